@@ -1,0 +1,39 @@
+/* Quantize / dequantize entry points.
+ * Replaces reference transformer_engine/common/include/transformer_engine/cast.h
+ * (definitions in common/cast/cast.cu:21-89).  Dispatch rule (ref
+ * common/cast/dispatch/quantize.cuh:63-93): the OUTPUT tensor's scaling mode picks
+ * the kernel - per-tensor scaling with a columnwise buffer -> cast+transpose,
+ * rowwise only -> flat cast, NVTE_MXFP8_1D_SCALING -> block-scaled cast.
+ */
+#ifndef TE_AMD_CAST_H_
+#define TE_AMD_CAST_H_
+
+#include "transformer_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ref cast.h:90 */
+void nvte_quantize(const NVTETensor input, NVTETensor output, hipStream_t stream);
+/* ref cast.h:115.  noop = fp32[1] on device; value 1.0f => kernel leaves outputs untouched. */
+void nvte_quantize_noop(const NVTETensor input, NVTETensor output, NVTETensor noop,
+                        hipStream_t stream);
+/* ref cast.h:125 */
+void nvte_quantize_v2(const NVTETensor input, NVTETensor output,
+                      const NVTEQuantizationConfig quant_config, hipStream_t stream);
+/* ref cast.h:145.  Two-call protocol: a call whose workspace has no data pointer only
+ * fills in the workspace shape/dtype and returns (ref transpose.h:48-49). */
+void nvte_quantize_dbias(const NVTETensor input, NVTETensor output, NVTETensor dbias,
+                         NVTETensor workspace, hipStream_t stream);
+/* ref cast.h:419 */
+void nvte_dequantize(const NVTETensor input, NVTETensor output, hipStream_t stream);
+/* ref cast.h:440 */
+void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
+                                const NVTEQuantizationConfig quant_config, const size_t num_tensors,
+                                hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

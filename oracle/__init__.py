@@ -1,0 +1,273 @@
+"""CPU oracle for the FP8 linear hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package.  It wraps ``oracle/te_oracle.c`` (a C restatement of the reference's
+``tests/cpp`` host references; every C function cites the reference lines it follows)
+with numpy-friendly helpers.  Nothing under ``transformer_engine_amd/`` imports it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libte_oracle.so")
+
+E4M3, E5M2 = 0, 1
+FP8_MAX = {E4M3: 448.0, E5M2: 57344.0}
+# NVTEDType values
+DT_F32, DT_F16, DT_BF16 = 4, 5, 6
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "te_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)
+    ):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        c = ctypes
+        L.te_float_to_fp8.restype = c.c_uint8
+        L.te_float_to_fp8.argtypes = [c.c_float, c.c_int]
+        L.te_fp8_to_float.restype = c.c_float
+        L.te_fp8_to_float.argtypes = [c.c_uint8, c.c_int]
+        L.te_float_to_e8m0.restype = c.c_uint8
+        L.te_float_to_e8m0.argtypes = [c.c_float]
+        L.te_exp2f_rcp.restype = c.c_float
+        L.te_exp2f_rcp.argtypes = [c.c_uint8]
+        L.te_e8m0_to_float.restype = c.c_float
+        L.te_e8m0_to_float.argtypes = [c.c_uint8]
+        L.te_float_to_bf16.restype = c.c_uint16
+        L.te_float_to_bf16.argtypes = [c.c_float]
+        L.te_float_to_half.restype = c.c_uint16
+        L.te_float_to_half.argtypes = [c.c_float]
+        L.te_half_to_float.restype = c.c_float
+        L.te_half_to_float.argtypes = [c.c_uint16]
+        for name in ("te_cast_transpose_ref", "te_cast_transpose_ref_omp"):
+            f = getattr(L, name)
+            f.restype = None
+            f.argtypes = [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t,
+                          c.c_float, c.c_int, c.c_void_p, c.c_void_p]
+        L.te_amax_ref.restype = c.c_float
+        L.te_amax_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t]
+        L.te_scale_from_amax_ref.restype = c.c_float
+        L.te_scale_from_amax_ref.argtypes = [c.c_float, c.c_float, c.c_int, c.c_float]
+        L.te_mxfp8_ref.restype = None
+        L.te_mxfp8_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_int, c.c_void_p,
+                                   c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p, c.c_size_t]
+        L.te_swizzle_scales_ref.restype = None
+        L.te_swizzle_scales_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t]
+        L.te_swizzle_col_scales_ref.restype = None
+        L.te_swizzle_col_scales_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t]
+        L.te_delayed_scaling_ref.restype = None
+        L.te_delayed_scaling_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                                             c.c_size_t, c.c_size_t, c.c_int, c.c_float, c.c_float]
+        L.te_delayed_scaling_bulk_ref.restype = None
+        L.te_delayed_scaling_bulk_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t,
+                                                  c.c_size_t, c.c_int, c.c_float, c.c_float]
+        L.te_dequant_ref.restype = None
+        L.te_dequant_ref.argtypes = [c.c_void_p, c.c_int, c.c_float, c.c_void_p, c.c_size_t]
+        L.te_dequant_mxfp8_ref.restype = None
+        L.te_dequant_mxfp8_ref.argtypes = [c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_int,
+                                           c.c_void_p, c.c_size_t, c.c_size_t]
+        L.te_gemm_tn_f32_ref.restype = None
+        L.te_gemm_tn_f32_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t,
+                                         c.c_size_t, c.c_float, c.c_float]
+        L.te_gemm_tn_f32_fast.restype = None
+        L.te_gemm_tn_f32_fast.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t,
+                                          c.c_size_t, c.c_size_t]
+        L.te_colsum_ref.restype = None
+        L.te_colsum_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_void_p]
+        L.te_oracle_num_threads.restype = c.c_int
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _in_dtype(a: np.ndarray) -> int:
+    """bf16 travels as uint16 (numpy has no bfloat16); fp16 as float16; fp32 as float32."""
+    if a.dtype == np.float32:
+        return DT_F32
+    if a.dtype == np.float16:
+        return DT_F16
+    if a.dtype == np.uint16:
+        return DT_BF16
+    raise TypeError(f"unsupported oracle input dtype {a.dtype}")
+
+
+def float_to_fp8(x: np.ndarray, fmt: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(x.shape, dtype=np.uint8)
+    flat_in, flat_out = x.reshape(-1), out.reshape(-1)
+    # reuse the cast_transpose reference with scale 1 and no transpose: vectorised in C
+    lib().te_cast_transpose_ref(_ptr(flat_in), DT_F32, _ptr(flat_out), None, 1, flat_in.size,
+                                ctypes.c_float(1.0), fmt, None, None)
+    return out
+
+
+def fp8_to_float(q: np.ndarray, fmt: int) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    out = np.empty(q.shape, dtype=np.float32)
+    lib().te_dequant_ref(_ptr(q), fmt, ctypes.c_float(1.0), _ptr(out), q.size)
+    return out
+
+
+def cast_transpose(x: np.ndarray, scale: float, fmt: int, transpose: bool = True, omp: bool = False):
+    """Returns (out_c [N,H] u8, out_t [H,N] u8 or None, amax f32, scale_inv f32)."""
+    x = np.ascontiguousarray(x)
+    n = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    h = x.shape[-1] if x.ndim >= 1 else 1
+    out_c = np.empty((n, h), dtype=np.uint8)
+    out_t = np.empty((h, n), dtype=np.uint8) if transpose else None
+    amax = np.zeros(1, dtype=np.float32)
+    sinv = np.zeros(1, dtype=np.float32)
+    fn = lib().te_cast_transpose_ref_omp if omp else lib().te_cast_transpose_ref
+    fn(_ptr(x), _in_dtype(x), _ptr(out_c), _ptr(out_t), n, h, ctypes.c_float(scale), fmt,
+       _ptr(amax), _ptr(sinv))
+    return out_c, out_t, amax[0], sinv[0]
+
+
+def amax(x: np.ndarray) -> np.float32:
+    x = np.ascontiguousarray(x)
+    return np.float32(lib().te_amax_ref(_ptr(x), _in_dtype(x), x.size))
+
+
+def scale_from_amax(amax_v: float, fmt: int, force_pow_2: bool = False, epsilon: float = 0.0) -> np.float32:
+    return np.float32(lib().te_scale_from_amax_ref(ctypes.c_float(amax_v), ctypes.c_float(FP8_MAX[fmt]),
+                                                   int(force_pow_2), ctypes.c_float(epsilon)))
+
+
+def round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def mxfp8_scale_shapes(rows: int, cols: int):
+    """(rowwise, columnwise) padded scale shapes (ref common/transformer_engine.cpp:93-115)."""
+    return ((round_up(rows, 128), round_up((cols + 31) // 32, 4)),
+            (round_up((rows + 31) // 32, 4), round_up(cols, 128)))
+
+
+def mxfp8(x: np.ndarray, fmt: int, rowwise: bool = True, colwise: bool = True):
+    """Returns dict with out_row, sc_row, out_col, sc_col (padding entries of scales = 0)."""
+    x = np.ascontiguousarray(x)
+    rows = int(np.prod(x.shape[:-1]))
+    cols = x.shape[-1]
+    rs, cs = mxfp8_scale_shapes(rows, cols)
+    res = {}
+    out_row = np.zeros((rows, cols), np.uint8) if rowwise else None
+    sc_row = np.zeros(rs, np.uint8) if rowwise else None
+    out_col = np.zeros((rows, cols), np.uint8) if colwise else None
+    sc_col = np.zeros(cs, np.uint8) if colwise else None
+    lib().te_mxfp8_ref(_ptr(x), _in_dtype(x), rows, cols, fmt, _ptr(out_row), _ptr(sc_row), rs[1],
+                       _ptr(out_col), _ptr(sc_col), cs[1])
+    res.update(out_row=out_row, sc_row=sc_row, out_col=out_col, sc_col=sc_col)
+    return res
+
+
+def swizzle_scales(sc: np.ndarray) -> np.ndarray:
+    sc = np.ascontiguousarray(sc, dtype=np.uint8)
+    out = np.zeros(sc.size, np.uint8)
+    lib().te_swizzle_scales_ref(_ptr(sc), _ptr(out), sc.shape[0], sc.shape[1])
+    return out
+
+
+def swizzle_col_scales(sc: np.ndarray) -> np.ndarray:
+    sc = np.ascontiguousarray(sc, dtype=np.uint8)
+    out = np.zeros(sc.size, np.uint8)
+    lib().te_swizzle_col_scales_ref(_ptr(sc), _ptr(out), sc.shape[0], sc.shape[1])
+    return out
+
+
+def delayed_scaling(hist: np.ndarray, scale: np.ndarray, algo: str, fmt: int, margin: float = 0.0):
+    hist = np.ascontiguousarray(hist, np.float32)
+    scale = np.ascontiguousarray(scale, np.float32)
+    nh, ns = np.empty_like(hist), np.empty_like(scale)
+    lib().te_delayed_scaling_ref(_ptr(hist), _ptr(scale), _ptr(nh), _ptr(ns), hist.shape[0],
+                                 hist.shape[1], 1 if algo == "max" else 0,
+                                 ctypes.c_float(FP8_MAX[fmt]), ctypes.c_float(margin))
+    return nh, ns
+
+
+def delayed_scaling_bulk(reduced, hist: np.ndarray, scale: np.ndarray, algo: str, fmt: int,
+                         margin: float = 0.0):
+    hist = np.array(hist, np.float32, copy=True, order="C")
+    scale = np.array(scale, np.float32, copy=True, order="C")
+    red = None if reduced is None else np.ascontiguousarray(reduced, np.float32)
+    lib().te_delayed_scaling_bulk_ref(_ptr(red), _ptr(hist), _ptr(scale), hist.shape[0],
+                                      hist.shape[1], 1 if algo == "max" else 0,
+                                      ctypes.c_float(FP8_MAX[fmt]), ctypes.c_float(margin))
+    return hist, scale
+
+
+def dequant(q: np.ndarray, fmt: int, scale_inv: float) -> np.ndarray:
+    q = np.ascontiguousarray(q, np.uint8)
+    out = np.empty(q.shape, np.float32)
+    lib().te_dequant_ref(_ptr(q), fmt, ctypes.c_float(scale_inv), _ptr(out), q.size)
+    return out
+
+
+def dequant_mxfp8(q: np.ndarray, fmt: int, sc: np.ndarray, rowwise: bool) -> np.ndarray:
+    q = np.ascontiguousarray(q, np.uint8)
+    sc = np.ascontiguousarray(sc, np.uint8)
+    out = np.empty(q.shape, np.float32)
+    lib().te_dequant_mxfp8_ref(_ptr(q), fmt, _ptr(sc), sc.shape[1], int(rowwise), _ptr(out),
+                               q.shape[0], q.shape[1])
+    return out
+
+
+def gemm_tn(P: np.ndarray, Q: np.ndarray, alpha: float = 1.0, beta: float = 0.0, D=None,
+            fast: bool = False) -> np.ndarray:
+    """D[i, j] = alpha * sum_k P[i, k] Q[j, k] + beta * D."""
+    P = np.ascontiguousarray(P, np.float32)
+    Q = np.ascontiguousarray(Q, np.float32)
+    n, k = P.shape
+    m = Q.shape[0]
+    out = np.zeros((n, m), np.float32) if D is None else np.array(D, np.float32, copy=True, order="C")
+    if fast:
+        lib().te_gemm_tn_f32_fast(_ptr(P), _ptr(Q), _ptr(out), n, m, k)
+    else:
+        lib().te_gemm_tn_f32_ref(_ptr(P), _ptr(Q), _ptr(out), n, m, k, ctypes.c_float(alpha),
+                                 ctypes.c_float(beta))
+    return out
+
+
+def colsum(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x)
+    rows = int(np.prod(x.shape[:-1]))
+    out = np.zeros(x.shape[-1], np.float32)
+    lib().te_colsum_ref(_ptr(x), _in_dtype(x), rows, x.shape[-1], _ptr(out))
+    return out
+
+
+def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round-to-nearest-even."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    r[nan] = ((u[nan] >> 16) | 0x40).astype(np.uint16)
+    return r
+
+
+def bf16_bits_to_float(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def num_threads() -> int:
+    return int(lib().te_oracle_num_threads())

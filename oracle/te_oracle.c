@@ -1,0 +1,419 @@
+/* TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's FP8 linear hot path, used ONLY as the parity
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing
+ * under transformer_engine_amd/ may import, link or call this file.
+ *
+ * Every function cites the reference lines it follows ("ref" = /root/reference).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - float -> FP8 (RNE, saturate-to-finite): checked exhaustively against torch's CPU
+ *     float8_e4m3fn / float8_e5m2 casts for every in-range fp32 bit pattern class and
+ *     against ROCm's host-side __hip_fp8 conversions incl. saturation
+ *     (tests/test_oracle_pinning.py).  NaN -> 0xFF (E4M3) / 0xFE (E5M2) is what the
+ *     gfx950 converter returns; the reference's tests never feed NaN to a cast, so the
+ *     NaN code points are "parity unpinned".
+ *   - scale-from-amax: checked against the reference's own pure-torch
+ *     tests/pytorch/references/quantize_scale_calc.py (imported by file path) and the
+ *     golden vectors generated from it (tests/golden/).
+ *   - e8m0 helpers: transcribed semantics of ref tests/cpp/test_common.h:480-513, checked
+ *     against torch.float8_e8m0fnu where they overlap.
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -shared).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TE_E4M3 0
+#define TE_E5M2 1
+
+/* ---------------------------------------------------------------- bit helpers */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float te_bf16_to_float(uint16_t b) { return u2f((uint32_t)b << 16); }
+
+/* fp32 -> bf16, round-to-nearest-even, NaN kept quiet (what a plain cast does). */
+uint16_t te_float_to_bf16(float f) {
+  uint32_t u = f2u(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+float te_half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+  if (e == 0) {
+    if (m == 0) return u2f(sign);
+    /* subnormal: normalise */
+    int shift = 0;
+    while (!(m & 0x400u)) { m <<= 1; ++shift; }
+    m &= 0x3FFu;
+    return u2f(sign | ((uint32_t)(113 - shift) << 23) | (m << 13));
+  }
+  if (e == 31) return u2f(sign | 0x7F800000u | (m << 13));
+  return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+uint16_t te_float_to_half(float f) {
+  const uint32_t u = f2u(f);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  const uint32_t a = u & 0x7FFFFFFFu;
+  if (a > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);
+  if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u); /* >= 65520 rounds to inf */
+  if (a < 0x33000001u) return (uint16_t)sign;               /* < 2^-25 (or tie to 0) */
+  int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7FFFFFu) | 0x800000u;
+  int shift;
+  uint32_t base;
+  if (e < -14) { shift = 13 + (-14 - e); base = 0; } else { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7FFFFFu; }
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+  if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+  return (uint16_t)(sign | (base + q));
+}
+
+/* ---------------------------------------------------------------- FP8 <-> float
+ * The reference casts with CUDA's __nv_fp8_e4m3 / __nv_fp8_e5m2 constructors
+ * (ref tests/cpp/test_common.h:67-68, common/common.h:645-646) = cvt.rn.satfinite
+ * (ref common/util/ptx.cuh:973,993): round-to-nearest-even, finite overflow AND
+ * infinity saturate to +-448 / +-57344, NaN -> NaN code.
+ */
+uint8_t te_float_to_fp8(float x, int fmt) {
+  const int man_bits = (fmt == TE_E4M3) ? 3 : 2;
+  const int bias = (fmt == TE_E4M3) ? 7 : 15;
+  const float maxv = (fmt == TE_E4M3) ? 448.f : 57344.f;
+  const uint8_t maxcode = (fmt == TE_E4M3) ? 0x7E : 0x7B;
+  const uint32_t u = f2u(x);
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80u);
+  /* NaN: the gfx950 converters (v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32) return ONE code for every
+   * NaN input whatever its sign or payload: 0xFF (E4M3, S.1111.111) and 0xFE (E5M2,
+   * S.11111.10) - measured.  CUDA's converter would give 0x7F / 0x7E-class codes; the reference's
+   * tests never cast a NaN, so these code points are "parity unpinned". */
+  if (x != x) return (uint8_t)((fmt == TE_E4M3) ? 0xFF : 0xFE);
+  const float ax = fabsf(x);
+  if (ax >= maxv) return (uint8_t)(sign | maxcode); /* includes +-inf */
+  if (ax == 0.f) return sign;
+  /* Represent ax = q * 2^(emin - man_bits) in the subnormal range, or 1.m * 2^e. */
+  int e;
+  (void)frexpf(ax, &e); /* ax = f * 2^e, f in [0.5,1) -> unbiased exponent e-1 */
+  int ue = e - 1;
+  const int emin = 1 - bias;
+  if (ue < emin) ue = emin; /* subnormal: fixed quantum */
+  /* quantum = 2^(ue - man_bits); the scaled value is exact in double */
+  const double scaled = ldexp((double)ax, man_bits - ue); /* in [0, 2^(man_bits+1)) */
+  double fl = floor(scaled);
+  const double rem = scaled - fl;
+  uint32_t q = (uint32_t)fl;
+  if (rem > 0.5 || (rem == 0.5 && (q & 1u))) ++q;
+  /* q in [0, 2^(man_bits+1)]; q == 2^(man_bits+1) means carry into the next binade */
+  uint32_t code;
+  if (ue == emin && q < (1u << man_bits)) {
+    code = q; /* subnormal (exponent field 0) */
+  } else {
+    uint32_t ef = (uint32_t)(ue + bias);
+    if (q == (2u << man_bits)) { q = 1u << man_bits; ++ef; }
+    code = (ef << man_bits) | (q - (1u << man_bits));
+  }
+  if (code > maxcode) code = maxcode; /* rounding up past max finite saturates */
+  return (uint8_t)(sign | code);
+}
+
+float te_fp8_to_float(uint8_t b, int fmt) {
+  const int man_bits = (fmt == TE_E4M3) ? 3 : 2;
+  const int bias = (fmt == TE_E4M3) ? 7 : 15;
+  const uint32_t ef = (b & 0x7Fu) >> man_bits, m = b & ((1u << man_bits) - 1u);
+  const float s = (b & 0x80u) ? -1.f : 1.f;
+  if (fmt == TE_E4M3) {
+    if ((b & 0x7Fu) == 0x7Fu) return s * NAN;
+  } else {
+    if (ef == 31) return m ? s * NAN : s * INFINITY;
+  }
+  if (ef == 0) return s * ldexpf((float)m, 1 - bias - man_bits);
+  return s * ldexpf((float)(m | (1u << man_bits)), (int)ef - bias - man_bits);
+}
+
+/* ref tests/cpp/test_common.h:480-500 (device twin common/util/ptx.cuh:386-417) */
+uint8_t te_float_to_e8m0(float val) {
+  if (val != val) return 0xFF;
+  if (isinf(val)) return 0xFE;
+  if (val == 0.0f) return 0x00;
+  const uint32_t u = f2u(val);
+  uint32_t exponent = (u >> 23) & 0xFFu; /* the reference stores the shifted word in a byte */
+  const uint32_t mantissa = u & 0x7FFFFFu;
+  if ((mantissa > 0 && exponent != 0xFE) && !(exponent == 0 && mantissa <= 0x400000u)) ++exponent;
+  return (uint8_t)exponent;
+}
+
+/* ref tests/cpp/test_common.h:502-513 */
+float te_exp2f_rcp(uint8_t biased_exp) {
+  uint32_t v;
+  if (biased_exp == 255) v = 0x7FFFFFFFu;
+  else if (biased_exp == 254) v = 0x00400000u;
+  else v = (uint32_t)(254 - biased_exp) << 23;
+  return u2f(v);
+}
+
+/* ref common/util/ptx.cuh:382-384 */
+float te_e8m0_to_float(uint8_t e) { return u2f((uint32_t)e << 23); }
+
+static inline float load_in(const void *p, size_t i, int in_dtype) {
+  switch (in_dtype) { /* NVTEDType values: 4 fp32, 5 fp16, 6 bf16 */
+    case 4: return ((const float *)p)[i];
+    case 5: return te_half_to_float(((const uint16_t *)p)[i]);
+    default: return te_bf16_to_float(((const uint16_t *)p)[i]);
+  }
+}
+
+/* ---------------------------------------------------------------- cast + transpose
+ * ref tests/cpp/operator/test_cast_transpose.cu:24-39 (compute_ref), plus the kernel-side
+ * details the test leaves implicit: scale==NULL means 1 (ref common/transpose/
+ * cast_transpose.cu:143), scale_inv = 1/scale (:213-215).  The test's serial double loop
+ * is kept serial on purpose: it is the reference's CPU cost (bench cpu_baseline).
+ */
+void te_cast_transpose_ref(const void *in, int in_dtype, uint8_t *out_c, uint8_t *out_t, size_t N,
+                           size_t H, float scale, int fmt, float *amax, float *scale_inv) {
+  float current_max = 0.f; /* reference starts at -1e100 and takes fmaxf(.., |x|): same for N*H>0 */
+  for (size_t i = 0; i < N; ++i) {
+    for (size_t j = 0; j < H; ++j) {
+      const float current = load_in(in, i * H + j, in_dtype);
+      current_max = fmaxf(current_max, fabsf(current));
+      const uint8_t q = te_float_to_fp8(scale * current, fmt);
+      if (out_c) out_c[i * H + j] = q;
+      if (out_t) out_t[j * N + i] = q;
+    }
+  }
+  if (amax) *amax = current_max;
+  if (scale_inv) *scale_inv = 1.0f / scale;
+}
+
+/* Same math, rows split over OpenMP threads (used as the "all host cores" baseline). */
+void te_cast_transpose_ref_omp(const void *in, int in_dtype, uint8_t *out_c, uint8_t *out_t,
+                               size_t N, size_t H, float scale, int fmt, float *amax,
+                               float *scale_inv) {
+  float gmax = 0.f;
+#pragma omp parallel for reduction(max : gmax) schedule(static)
+  for (long i = 0; i < (long)N; ++i) {
+    float m = 0.f;
+    for (size_t j = 0; j < H; ++j) {
+      const float current = load_in(in, (size_t)i * H + j, in_dtype);
+      m = fmaxf(m, fabsf(current));
+      const uint8_t q = te_float_to_fp8(scale * current, fmt);
+      if (out_c) out_c[(size_t)i * H + j] = q;
+      if (out_t) out_t[j * N + (size_t)i] = q;
+    }
+    gmax = fmaxf(gmax, m);
+  }
+  if (amax) *amax = gmax;
+  if (scale_inv) *scale_inv = 1.0f / scale;
+}
+
+/* ---------------------------------------------------------------- current scaling
+ * ref tests/cpp/operator/test_cast_transpose_current_scaling.cu:41-88 and the device
+ * function ref common/recipe/recipe_common.cuh:14-49 (epsilon floor, pow2, NaN).
+ */
+float te_amax_ref(const void *in, int in_dtype, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(load_in(in, i, in_dtype)));
+  return m;
+}
+
+float te_scale_from_amax_ref(float amax, float max_fp8, int force_pow_2, float epsilon) {
+  if (amax < epsilon) amax = epsilon;
+  if (isinf(amax) || amax == 0.f || amax != amax) return 1.f;
+  float scale = max_fp8 / amax;
+  if (isinf(scale)) scale = 3.402823466e+38f;
+  if (force_pow_2) scale = u2f(f2u(scale) & 0xFF800000u);
+  return scale;
+}
+
+/* ---------------------------------------------------------------- MXFP8
+ * ref tests/cpp/operator/test_cast_mxfp8.cu:39-166 (CAST_ONLY path): 32x32 tiles; rowwise
+ * blocks 1x32, columnwise blocks 32x1; e = float_to_e8m0(amax * (1/fp8_max));
+ * q = fp8(x * exp2f_rcp(e)).  Scale strides are the PADDED row lengths.
+ */
+void te_mxfp8_ref(const void *in, int in_dtype, size_t rows, size_t cols, int fmt,
+                  uint8_t *out_row, uint8_t *sc_row, size_t stride_row, uint8_t *out_col,
+                  uint8_t *sc_col, size_t stride_col) {
+  const float max_rcp = (float)(1.0 / (double)((fmt == TE_E4M3) ? 448.f : 57344.f));
+  const size_t ty = (rows + 31) / 32, tx = (cols + 31) / 32;
+#pragma omp parallel for schedule(static)
+  for (long t = 0; t < (long)(ty * tx); ++t) {
+    const size_t tile_Y = (size_t)t / tx, tile_X = (size_t)t % tx;
+    const size_t i0 = tile_Y * 32, i1 = (i0 + 32 < rows) ? i0 + 32 : rows;
+    const size_t j0 = tile_X * 32, j1 = (j0 + 32 < cols) ? j0 + 32 : cols;
+    float cache[32][32];
+    for (size_t i = i0; i < i1; ++i)
+      for (size_t j = j0; j < j1; ++j) cache[i - i0][j - j0] = load_in(in, i * cols + j, in_dtype);
+    if (out_row) {
+      for (size_t i = i0; i < i1; ++i) {
+        float block_amax = 0.f;
+        for (size_t j = j0; j < j1; ++j) {
+          const float a = fabsf(cache[i - i0][j - j0]);
+          if (block_amax < a) block_amax = a; /* std::max(a,b): NaN b is ignored */
+        }
+        const uint8_t e = te_float_to_e8m0(block_amax * max_rcp);
+        sc_row[i * stride_row + tile_X] = e;
+        const float r = te_exp2f_rcp(e);
+        for (size_t j = j0; j < j1; ++j) out_row[i * cols + j] = te_float_to_fp8(cache[i - i0][j - j0] * r, fmt);
+      }
+    }
+    if (out_col) {
+      for (size_t j = j0; j < j1; ++j) {
+        float block_amax = 0.f;
+        for (size_t i = i0; i < i1; ++i) {
+          const float a = fabsf(cache[i - i0][j - j0]);
+          if (block_amax < a) block_amax = a;
+        }
+        const uint8_t e = te_float_to_e8m0(block_amax * max_rcp);
+        sc_col[tile_Y * stride_col + j] = e;
+        const float r = te_exp2f_rcp(e);
+        for (size_t i = i0; i < i1; ++i) out_col[i * cols + j] = te_float_to_fp8(cache[i - i0][j - j0] * r, fmt);
+      }
+    }
+  }
+}
+
+/* ref common/cast/mxfp8/swizzle.cuh:30-41 */
+size_t te_swizzled_scale_idx(size_t i, size_t j, size_t num_tiles_X) {
+  const size_t tile_idx_X = j / 4, tile_idx_Y = i / 128;
+  const size_t x = j % 4, y = i % 128;
+  return (tile_idx_Y * num_tiles_X + tile_idx_X) * 512 + (y % 32) * 16 + (y / 32) * 4 + x;
+}
+
+/* compact [M,K] (M % 128 == 0, K % 4 == 0) -> swizzled image */
+void te_swizzle_scales_ref(const uint8_t *in, uint8_t *out, size_t M, size_t K) {
+  for (size_t i = 0; i < M; ++i)
+    for (size_t j = 0; j < K; ++j) out[te_swizzled_scale_idx(i, j, K / 4)] = in[i * K + j];
+}
+
+/* columnwise scales: compact [KB, N] viewed as the transposed [N, KB] matrix
+ * (ref common/cast/mxfp8/quantize_mxfp8.cuh:273-278) */
+void te_swizzle_col_scales_ref(const uint8_t *in, uint8_t *out, size_t KB, size_t N) {
+  for (size_t j = 0; j < KB; ++j)
+    for (size_t i = 0; i < N; ++i) out[te_swizzled_scale_idx(i, j, KB / 4)] = in[j * N + i];
+}
+
+/* ---------------------------------------------------------------- delayed scaling
+ * ref common/recipe/delayed_scaling.cu:84-154 (one launch per history tensor) and the
+ * pure-torch twin ref transformer_engine/pytorch/quantization.py:1057-1106;
+ * expectations ref tests/pytorch/test_recipe.py:116-189.
+ * algo: 0 = most_recent, 1 = max.  hist is [H, S] row-major; may run in place.
+ */
+static float ds_scale(float amax, float old_scale, float scaled_max) {
+  float s = (isfinite(amax) && amax > 0.f) ? scaled_max / amax : old_scale;
+  if (isinf(s)) s = 3.402823466e+38f;
+  return s;
+}
+
+void te_delayed_scaling_ref(const float *hist, const float *scale, float *new_hist, float *new_scale,
+                            size_t H, size_t S, int algo, float fp8_max, float margin) {
+  const float scaled_max = fp8_max * powf(2.f, -margin);
+  for (size_t s = 0; s < S; ++s) {
+    const float last = hist[s];
+    float amax = 0.f;
+    float prev_row0 = 0.f;
+    (void)prev_row0;
+    /* roll by -1: new[i] = old[i+1], new[H-1] = old[0]; then new[0] = 0 */
+    float carry = last;
+    for (size_t i = 0; i < H; ++i) {
+      const float a = (i + 1 < H) ? hist[(i + 1) * S + s] : carry;
+      amax = fmaxf(amax, a);
+      new_hist[i * S + s] = (i > 0) ? a : 0.f;
+    }
+    if (algo == 0) amax = last;
+    new_scale[s] = ds_scale(amax, scale[s], scaled_max);
+  }
+}
+
+/* ref common/recipe/delayed_scaling.cu:162-253 (bulk, after the amax all-reduce): `last` comes
+ * from the reduced buffer when that entry is non-zero; the roll is SKIPPED when last == 0. */
+void te_delayed_scaling_bulk_ref(const float *reduced /*may be NULL*/, float *hist, float *scale,
+                                 size_t H, size_t S, int algo, float fp8_max, float margin) {
+  const float scaled_max = fp8_max * powf(2.f, -margin);
+  for (size_t s = 0; s < S; ++s) {
+    float last = hist[s];
+    if (reduced && reduced[s] != 0.0f) last = reduced[s];
+    float amax = 0.f;
+    if (last != 0.0f) {
+      for (size_t i = 0; i < H; ++i) {
+        const float a = (i + 1 < H) ? hist[(i + 1) * S + s] : last;
+        amax = fmaxf(amax, a);
+        hist[i * S + s] = (i > 0) ? a : 0.f;
+      }
+    }
+    if (algo == 0) amax = last;
+    scale[s] = ds_scale(amax, scale[s], scaled_max);
+  }
+}
+
+/* ---------------------------------------------------------------- dequantize + FP32 GEMM
+ * The reference has no host GEMM (ref tests/cpp/operator/test_grouped_gemm.cu:366); its
+ * contract is "within tolerance of the matmul of the dequantized operands"
+ * (ref tests/pytorch/utils.py:97-104).  D[i][j] = alpha * sum_k P[i][k] Q[j][k] + beta * D.
+ */
+void te_dequant_ref(const uint8_t *q, int fmt, float scale_inv, float *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) out[i] = te_fp8_to_float(q[i], fmt) * scale_inv;
+}
+
+void te_dequant_mxfp8_ref(const uint8_t *q, int fmt, const uint8_t *sc, size_t stride, int rowwise,
+                          float *out, size_t rows, size_t cols) {
+  for (size_t i = 0; i < rows; ++i)
+    for (size_t j = 0; j < cols; ++j) {
+      const uint8_t e = rowwise ? sc[i * stride + j / 32] : sc[(i / 32) * stride + j];
+      out[i * cols + j] = te_fp8_to_float(q[i * cols + j], fmt) * te_e8m0_to_float(e);
+    }
+}
+
+void te_gemm_tn_f32_ref(const float *P, const float *Q, float *D, size_t n, size_t m, size_t k,
+                        float alpha, float beta) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)n; ++i) {
+    for (size_t j = 0; j < m; ++j) {
+      const float *p = P + (size_t)i * k, *q = Q + j * k;
+      double acc = 0.0; /* wide accumulator: the oracle should not add its own rounding noise */
+      for (size_t kk = 0; kk < k; ++kk) acc += (double)p[kk] * (double)q[kk];
+      const float prev = (beta != 0.f) ? D[(size_t)i * m + j] : 0.f;
+      D[(size_t)i * m + j] = (float)(alpha * acc) + beta * prev;
+    }
+  }
+}
+
+/* Faster blocked float-accumulate variant, used only as the CPU baseline timing leg. */
+void te_gemm_tn_f32_fast(const float *P, const float *Q, float *D, size_t n, size_t m, size_t k) {
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)n; ++i) {
+    for (size_t j = 0; j < m; ++j) {
+      const float *p = P + (size_t)i * k, *q = Q + j * k;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      size_t kk = 0;
+      for (; kk + 4 <= k; kk += 4) {
+        a0 += p[kk] * q[kk]; a1 += p[kk + 1] * q[kk + 1];
+        a2 += p[kk + 2] * q[kk + 2]; a3 += p[kk + 3] * q[kk + 3];
+      }
+      for (; kk < k; ++kk) a0 += p[kk] * q[kk];
+      D[(size_t)i * m + j] = (a0 + a1) + (a2 + a3);
+    }
+  }
+}
+
+void te_colsum_ref(const void *in, int in_dtype, size_t rows, size_t cols, float *out) {
+  for (size_t j = 0; j < cols; ++j) out[j] = 0.f;
+  for (size_t i = 0; i < rows; ++i)
+    for (size_t j = 0; j < cols; ++j) out[j] += load_in(in, i * cols + j, in_dtype);
+}
+
+int te_oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

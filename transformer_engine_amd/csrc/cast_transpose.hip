@@ -1,0 +1,459 @@
+// Per-tensor-scaled quantize kernels: cast + transpose (+amax, +scale_inv) and the
+// flat rowwise cast.  HBM-bound: 2 B read + 1 B (+1 B) written per bf16 element.
+//
+// Replaces (behaviour, not structure):
+//   ref common/transpose/cast_transpose.cu:104-216 (general kernel), :220-344 (launcher),
+//       common/transpose/rtc/cast_transpose.cu:24-129 (tuned aligned kernel),
+//       common/util/vectorized_pointwise.h:176-227 (rowwise cast),
+//       common/cast/fp8/quantize_fp8.cuh:510-573 (rowwise dispatch).
+//
+// MI355X design of the aligned path: one 256-thread workgroup owns a 128x128 element
+// tile.  Thread (cg = t%16, rg = t/16) loads an 8-row x 8-column block with eight
+// 16-byte loads (a wave instruction covers four 256-byte row segments), converts with
+// v_cvt_pk_{fp8,bf8}_f32, stores the rowwise bytes straight from registers (8 B per
+// lane, 128 B contiguous per 16 lanes), transposes its 8x8 byte block in registers
+// with v_perm_b32 and writes eight 8-byte column pieces into a 16 KiB XOR-swizzled LDS
+// image of the transposed tile.  After one barrier every thread reads 16 bytes per
+// pass and stores them with 16-byte stores: a wave instruction writes eight full
+// 128-byte lines of the transposed output.  Both LDS phases are bank-conflict free
+// (see DESIGN.md for the bank arithmetic).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "device_utils.h"
+
+namespace te {
+namespace {
+
+constexpr int kTile = 128;      // tile edge, elements
+constexpr int kCtThreads = 256;
+
+// ---------------------------------------------------------------- 8-element loads
+template <typename IT>
+struct Load8;
+
+template <>
+struct Load8<bf16_t> {
+  static __device__ __forceinline__ void run(const bf16_t *p, float (&f)[8]) {
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = __uint_as_float(v[k] << 16);
+      f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
+    }
+  }
+};
+
+template <>
+struct Load8<f16_t> {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void run(const f16_t *p, float (&f)[8]) {
+    const h8 v = *reinterpret_cast<const h8 *>(p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(v[k]);
+  }
+};
+
+template <>
+struct Load8<float> {
+  static __device__ __forceinline__ void run(const float *p, float (&f)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(p + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] = a[k];
+      f[4 + k] = b[k];
+    }
+  }
+};
+
+// ---------------------------------------------------------------- aligned 128x128 tile kernel
+// Requires rows % 128 == 0, cols % 128 == 0, 16-byte aligned base pointers.
+template <typename IT, Fp8 F>
+__global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
+    const IT *__restrict__ in, const float *__restrict__ noop, uint8_t *__restrict__ out_c,
+    uint8_t *__restrict__ out_t, const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
+    float *__restrict__ scale_inv_ptr, const size_t rows, const size_t cols, const unsigned tiles_c) {
+  if (noop_set(noop)) return;
+
+  __shared__ __attribute__((aligned(16))) uint8_t tile_t[kTile * kTile];
+  __shared__ float red[kCtThreads / kWave];
+
+  const unsigned t = threadIdx.x;
+  const unsigned cg = t & 15u;   // 8-column group
+  const unsigned rg = t >> 4;    // 8-row group
+  const size_t tile_r = blockIdx.x / tiles_c;
+  const size_t tile_col = blockIdx.x % tiles_c;
+  const size_t row0 = tile_r * kTile + rg * 8;
+  const size_t col0 = tile_col * kTile + cg * 8;
+
+  const float scale = scale_ptr ? *scale_ptr : 1.0f;
+  float amax = 0.f;
+
+  // q[i][h]: row i of this thread's block, columns 4h..4h+3
+  uint32_t q[8][2];
+  {
+    float f[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) Load8<IT>::run(in + (row0 + i) * cols + col0, f[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, __builtin_fabsf(f[i][j]));
+      q[i][0] = cvt4_fp8<F>(f[i][0] * scale, f[i][1] * scale, f[i][2] * scale, f[i][3] * scale);
+      q[i][1] = cvt4_fp8<F>(f[i][4] * scale, f[i][5] * scale, f[i][6] * scale, f[i][7] * scale);
+    }
+  }
+
+  // rowwise output straight from registers
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u32x2 v = {q[i][0], q[i][1]};
+    *reinterpret_cast<u32x2 *>(out_c + (row0 + i) * cols + col0) = v;
+  }
+
+  // 8x8 byte transpose as four 4x4 blocks
+  transpose4x4_bytes(q[0][0], q[1][0], q[2][0], q[3][0]);  // rows 0-3, cols 0-3
+  transpose4x4_bytes(q[0][1], q[1][1], q[2][1], q[3][1]);  // rows 0-3, cols 4-7
+  transpose4x4_bytes(q[4][0], q[5][0], q[6][0], q[7][0]);  // rows 4-7, cols 0-3
+  transpose4x4_bytes(q[4][1], q[5][1], q[6][1], q[7][1]);  // rows 4-7, cols 4-7
+  // now q[j][h] = column 4h+j, rows 0-3 ; q[4+j][h] = column 4h+j, rows 4-7
+
+  // LDS image of the transposed tile: row c (128 B) holds the 16 eight-row chunks of
+  // column c; chunk rg sits at slot (rg ^ (c/8)).
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned c = cg * 8 + h * 4 + j;
+      u32x2 v = {q[j][h], q[4 + j][h]};
+      *reinterpret_cast<u32x2 *>(&tile_t[c * kTile + ((rg ^ cg) << 3)]) = v;
+    }
+  }
+  __syncthreads();
+
+  // transposed output: 4 passes, 16 B per thread per pass
+  const unsigned k = t & 7u;  // 16-row chunk of the output row
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned c = (t >> 3) + 32u * p;
+    const unsigned cgc = c >> 3;
+    u32x4 v = *reinterpret_cast<const u32x4 *>(&tile_t[c * kTile + ((k ^ (cgc >> 1)) << 4)]);
+    if (cgc & 1u) {
+      u32x4 w = {v[2], v[3], v[0], v[1]};
+      v = w;
+    }
+    *reinterpret_cast<u32x4 *>(out_t + (tile_col * kTile + c) * rows + tile_r * kTile + k * 16) = v;
+  }
+
+  if (amax_ptr != nullptr) {
+    amax = block_max<kCtThreads / kWave>(amax, red);
+    if (t == 0) atomic_max_nonneg(amax_ptr, amax);
+  }
+  if (blockIdx.x == 0 && t == 0 && scale_inv_ptr != nullptr) *scale_inv_ptr = 1.0f / scale;
+}
+
+// ---------------------------------------------------------------- general kernel (any shape, any dtype pair)
+template <typename OT>
+struct OutCvt;
+template <>
+struct OutCvt<float> {
+  static __device__ __forceinline__ float run(float x) { return x; }
+};
+template <>
+struct OutCvt<bf16_t> {
+  static __device__ __forceinline__ bf16_t run(float x) {
+    bf16_t o;
+    narrow(x, o);
+    return o;
+  }
+};
+template <>
+struct OutCvt<f16_t> {
+  static __device__ __forceinline__ f16_t run(float x) {
+    f16_t o;
+    narrow(x, o);
+    return o;
+  }
+};
+struct e4m3_t {
+  uint8_t b;
+};
+struct e5m2_t {
+  uint8_t b;
+};
+template <>
+struct OutCvt<e4m3_t> {
+  static __device__ __forceinline__ e4m3_t run(float x) { return e4m3_t{cvt1_fp8<Fp8::E4M3>(x)}; }
+};
+template <>
+struct OutCvt<e5m2_t> {
+  static __device__ __forceinline__ e5m2_t run(float x) { return e5m2_t{cvt1_fp8<Fp8::E5M2>(x)}; }
+};
+
+constexpr int kGTile = 64;
+
+template <typename IT, typename OT, bool WITH_T>
+__global__ __launch_bounds__(256) void cast_transpose_general_kernel(
+    const IT *__restrict__ in, const float *__restrict__ noop, OT *__restrict__ out_c,
+    OT *__restrict__ out_t, const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
+    float *__restrict__ scale_inv_ptr, const size_t rows, const size_t cols, const unsigned tiles_c) {
+  if (noop_set(noop)) return;
+  __shared__ OT tile[WITH_T ? kGTile : 1][kGTile + 1];
+  __shared__ float red[4];
+
+  const unsigned t = threadIdx.x;
+  const unsigned lx = t & 63u, ly = t >> 6;
+  const size_t r_base = static_cast<size_t>(blockIdx.x / tiles_c) * kGTile;
+  const size_t c_base = static_cast<size_t>(blockIdx.x % tiles_c) * kGTile;
+  const float scale = scale_ptr ? *scale_ptr : 1.0f;
+  float amax = 0.f;
+
+#pragma unroll 4
+  for (int i = 0; i < kGTile / 4; ++i) {
+    const size_t r = r_base + ly + 4 * i, c = c_base + lx;
+    if (r < rows && c < cols) {
+      const float x = widen(in[r * cols + c]);
+      amax = fmaxf(amax, __builtin_fabsf(x));
+      const OT o = OutCvt<OT>::run(x * scale);
+      if (out_c != nullptr) out_c[r * cols + c] = o;
+      if constexpr (WITH_T) tile[lx][ly + 4 * i] = o;
+    }
+  }
+  if constexpr (WITH_T) {
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < kGTile / 4; ++i) {
+      const size_t c = c_base + ly + 4 * i, r = r_base + lx;
+      if (r < rows && c < cols) out_t[c * rows + r] = tile[ly + 4 * i][lx];
+    }
+  }
+  if (amax_ptr != nullptr) {
+    amax = block_max<4>(amax, red);
+    if (t == 0) atomic_max_nonneg(amax_ptr, amax);
+  }
+  if (blockIdx.x == 0 && t == 0 && scale_inv_ptr != nullptr) *scale_inv_ptr = 1.0f / scale;
+}
+
+// ---------------------------------------------------------------- flat rowwise cast (aligned, FP8 out)
+// Each thread converts 16 consecutive elements per step: two 16 B loads (bf16/fp16) and
+// one 16 B store; grid-stride over the tensor.  N % 16 == 0 and 16 B aligned pointers.
+template <typename IT, Fp8 F>
+__global__ __launch_bounds__(256) void cast_flat_kernel(
+    const IT *__restrict__ in, const float *__restrict__ noop, uint8_t *__restrict__ out,
+    const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
+    float *__restrict__ scale_inv_ptr, const size_t n16) {
+  if (noop_set(noop)) return;
+  __shared__ float red[4];
+  const float scale = scale_ptr ? *scale_ptr : 1.0f;
+  float amax = 0.f;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    float f[16];
+    Load8<IT>::run(in + i * 16, reinterpret_cast<float(&)[8]>(f[0]));
+    Load8<IT>::run(in + i * 16 + 8, reinterpret_cast<float(&)[8]>(f[8]));
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, __builtin_fabsf(f[4 * k + j]));
+      o[k] = cvt4_fp8<F>(f[4 * k] * scale, f[4 * k + 1] * scale, f[4 * k + 2] * scale,
+                         f[4 * k + 3] * scale);
+    }
+    *reinterpret_cast<u32x4 *>(out + i * 16) = o;
+  }
+  if (amax_ptr != nullptr) {
+    amax = block_max<4>(amax, red);
+    if (threadIdx.x == 0) atomic_max_nonneg(amax_ptr, amax);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scale_inv_ptr != nullptr)
+    *scale_inv_ptr = 1.0f / scale;
+}
+
+// Scalar flat cast for shapes / alignments / dtype pairs the vector kernel does not take.
+template <typename IT, typename OT>
+__global__ __launch_bounds__(256) void cast_flat_general_kernel(
+    const IT *__restrict__ in, const float *__restrict__ noop, OT *__restrict__ out,
+    const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
+    float *__restrict__ scale_inv_ptr, const size_t n) {
+  if (noop_set(noop)) return;
+  __shared__ float red[4];
+  const float scale = scale_ptr ? *scale_ptr : 1.0f;
+  float amax = 0.f;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = widen(in[i]);
+    amax = fmaxf(amax, __builtin_fabsf(x));
+    out[i] = OutCvt<OT>::run(x * scale);
+  }
+  if (amax_ptr != nullptr) {
+    amax = block_max<4>(amax, red);
+    if (threadIdx.x == 0) atomic_max_nonneg(amax_ptr, amax);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && scale_inv_ptr != nullptr) *scale_inv_ptr = 1.0f / scale;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename IT, typename OT>
+void launch_general(const Tensor &in, const float *noop, Tensor &out, bool with_t, size_t rows,
+                    size_t cols, hipStream_t stream) {
+  const unsigned tiles_c = static_cast<unsigned>(ceil_div(cols, kGTile));
+  const size_t nblk = ceil_div(rows, kGTile) * tiles_c;
+  NVTE_CHECK(nblk < (1ull << 31), "tensor too large for the general cast kernel");
+  const IT *ip = static_cast<const IT *>(in.data.ptr);
+  OT *oc = static_cast<OT *>(out.data.ptr);
+  OT *ot = static_cast<OT *>(out.columnwise_data.ptr);
+  const float *sp = static_cast<const float *>(out.scale.ptr);
+  float *ap = static_cast<float *>(out.amax.ptr);
+  float *sip = static_cast<float *>(out.scale_inv.ptr);
+  if (with_t) {
+    hipLaunchKernelGGL((cast_transpose_general_kernel<IT, OT, true>), dim3(nblk), dim3(256), 0,
+                       stream, ip, noop, oc, ot, sp, ap, sip, rows, cols, tiles_c);
+  } else {
+    hipLaunchKernelGGL((cast_transpose_general_kernel<IT, OT, false>), dim3(nblk), dim3(256), 0,
+                       stream, ip, noop, oc, ot, sp, ap, sip, rows, cols, tiles_c);
+  }
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+template <typename IT>
+void launch_general_by_out(const Tensor &in, const float *noop, Tensor &out, bool with_t,
+                           size_t rows, size_t cols, hipStream_t stream) {
+  switch (out.data.dtype) {
+    case kNVTEFloat8E4M3: launch_general<IT, e4m3_t>(in, noop, out, with_t, rows, cols, stream); break;
+    case kNVTEFloat8E5M2: launch_general<IT, e5m2_t>(in, noop, out, with_t, rows, cols, stream); break;
+    case kNVTEFloat32: launch_general<IT, float>(in, noop, out, with_t, rows, cols, stream); break;
+    case kNVTEFloat16: launch_general<IT, f16_t>(in, noop, out, with_t, rows, cols, stream); break;
+    case kNVTEBFloat16: launch_general<IT, bf16_t>(in, noop, out, with_t, rows, cols, stream); break;
+    default: NVTE_ERROR("Unsupported output dtype ", dtype_name(out.data.dtype));
+  }
+}
+
+template <typename IT, Fp8 F>
+void launch_tile(const Tensor &in, const float *noop, Tensor &out, size_t rows, size_t cols,
+                 hipStream_t stream) {
+  const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
+  const size_t nblk = (rows / kTile) * tiles_c;
+  NVTE_CHECK(nblk < (1ull << 31), "tensor too large for the tile cast kernel");
+  hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, F>), dim3(nblk), dim3(kCtThreads), 0, stream,
+                     static_cast<const IT *>(in.data.ptr), noop,
+                     static_cast<uint8_t *>(out.data.ptr),
+                     static_cast<uint8_t *>(out.columnwise_data.ptr),
+                     static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
+                     static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c);
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+template <typename IT, Fp8 F>
+void launch_flat(const Tensor &in, const float *noop, Tensor &out, size_t n, hipStream_t stream) {
+  const size_t n16 = n / 16;
+  const DeviceInfo &di = device_info();
+  const size_t want = ceil_div(n16, 256);
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>(want, static_cast<size_t>(di.num_cus) * 8));
+  hipLaunchKernelGGL((cast_flat_kernel<IT, F>), dim3(grid), dim3(256), 0, stream,
+                     static_cast<const IT *>(in.data.ptr), noop, static_cast<uint8_t *>(out.data.ptr),
+                     static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
+                     static_cast<float *>(out.scale_inv.ptr), n16);
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+template <typename IT, typename OT>
+void launch_flat_general(const Tensor &in, const float *noop, Tensor &out, size_t n,
+                         hipStream_t stream) {
+  const DeviceInfo &di = device_info();
+  const unsigned grid = static_cast<unsigned>(
+      std::min<size_t>(ceil_div(n, 256), static_cast<size_t>(di.num_cus) * 16));
+  hipLaunchKernelGGL((cast_flat_general_kernel<IT, OT>), dim3(grid), dim3(256), 0, stream,
+                     static_cast<const IT *>(in.data.ptr), noop, static_cast<OT *>(out.data.ptr),
+                     static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
+                     static_cast<float *>(out.scale_inv.ptr), n);
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+template <typename IT>
+void launch_flat_general_by_out(const Tensor &in, const float *noop, Tensor &out, size_t n,
+                                hipStream_t stream) {
+  switch (out.data.dtype) {
+    case kNVTEFloat8E4M3: launch_flat_general<IT, e4m3_t>(in, noop, out, n, stream); break;
+    case kNVTEFloat8E5M2: launch_flat_general<IT, e5m2_t>(in, noop, out, n, stream); break;
+    case kNVTEFloat32: launch_flat_general<IT, float>(in, noop, out, n, stream); break;
+    case kNVTEFloat16: launch_flat_general<IT, f16_t>(in, noop, out, n, stream); break;
+    case kNVTEBFloat16: launch_flat_general<IT, bf16_t>(in, noop, out, n, stream); break;
+    default: NVTE_ERROR("Unsupported output dtype ", dtype_name(out.data.dtype));
+  }
+}
+
+#define TE_SWITCH_IN(dtype, IT, ...)                                        \
+  switch (dtype) {                                                          \
+    case kNVTEFloat32: { using IT = float; __VA_ARGS__; } break;            \
+    case kNVTEFloat16: { using IT = f16_t; __VA_ARGS__; } break;            \
+    case kNVTEBFloat16: { using IT = bf16_t; __VA_ARGS__; } break;          \
+    default: NVTE_ERROR("Unsupported input dtype ", dtype_name(dtype));     \
+  }
+
+}  // namespace
+
+// cast + transpose with shared scale / amax / scale_inv  (ref cast_transpose.cu:220-344)
+void cast_transpose_launch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream) {
+  check_input(in, "cast_transpose_input");
+  check_output(out, "cast_transpose_output");
+  NVTE_CHECK(in.has_data(), "Input is not allocated");
+  NVTE_CHECK(out.has_data(), "Output rowwise data is not allocated");
+  NVTE_CHECK(out.has_columnwise_data(), "Output columnwise is not allocated");
+  NVTE_CHECK(same_shape(in.data.shape, out.data.shape),
+             "Input and output shapes do not match (input=", in.data.shape,
+             ", output=", out.data.shape, ")");
+  NVTE_CHECK(!is_fp8(in.dtype()), "Input must be in higher precision.");
+  NVTE_CHECK(is_tensor_scaling(out.scaling_mode), "Not implemented scaling mode: ",
+             scaling_mode_name(out.scaling_mode));
+  const size_t rows = in.rows(), cols = in.cols();
+  NVTE_CHECK(out.columnwise_data.numel() == rows * cols, "Invalid columnwise output size (expected ",
+             rows * cols, " elements, got ", out.columnwise_data.numel(), ")");
+  NVTE_CHECK(out.data.dtype == out.columnwise_data.dtype,
+             "Cast and transposed output types must match.");
+  NVTE_CHECK(out.scale_inv.ptr == out.columnwise_scale_inv.ptr,
+             "Cast and transposed outputs need to share scale-inverse tensor.");
+  if (rows == 0 || cols == 0) return;
+
+  const bool fp8_out = is_fp8(out.data.dtype);
+  const bool fast = fp8_out && rows % kTile == 0 && cols % kTile == 0 && aligned16(in.data.ptr) &&
+                    aligned16(out.data.ptr) && aligned16(out.columnwise_data.ptr);
+  TE_SWITCH_IN(in.data.dtype, IT, {
+    if (fast) {
+      if (out.data.dtype == kNVTEFloat8E4M3)
+        launch_tile<IT, Fp8::E4M3>(in, noop, out, rows, cols, stream);
+      else
+        launch_tile<IT, Fp8::E5M2>(in, noop, out, rows, cols, stream);
+    } else {
+      launch_general_by_out<IT>(in, noop, out, true, rows, cols, stream);
+    }
+  });
+}
+
+// rowwise-only cast (ref quantize_fp8.cuh:510-573 + vectorized_pointwise.h:176-227)
+void cast_rowwise_launch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream) {
+  check_input(in, "cast_input");
+  check_output(out, "cast_output");
+  NVTE_CHECK(!is_fp8(in.dtype()), "Input must be in higher precision.");
+  NVTE_CHECK(in.has_data(), "Input is not allocated");
+  NVTE_CHECK(same_shape(out.data.shape, in.data.shape), "Input and output shapes need to match.");
+  NVTE_CHECK(is_tensor_scaling(out.scaling_mode), "Not implemented scaling mode: ",
+             scaling_mode_name(out.scaling_mode));
+  const size_t n = in.data.numel();
+  if (n == 0) return;
+  const bool fp8_out = is_fp8(out.data.dtype);
+  const bool fast = fp8_out && n % 16 == 0 && aligned16(in.data.ptr) && aligned16(out.data.ptr);
+  TE_SWITCH_IN(in.data.dtype, IT, {
+    if (fast) {
+      if (out.data.dtype == kNVTEFloat8E4M3)
+        launch_flat<IT, Fp8::E4M3>(in, noop, out, n, stream);
+      else
+        launch_flat<IT, Fp8::E5M2>(in, noop, out, n, stream);
+    } else {
+      launch_flat_general_by_out<IT>(in, noop, out, n, stream);
+    }
+  });
+}
+
+}  // namespace te

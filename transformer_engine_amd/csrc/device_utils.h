@@ -1,0 +1,197 @@
+// Device-side helpers shared by the quantize / transpose / recipe kernels (gfx950).
+//
+// Numerics contract (what the CPU oracle in oracle/te_oracle.c restates):
+//   * a value is widened to fp32, multiplied by the fp32 scale (ONE rounding), then
+//     converted to FP8 with round-to-nearest-even and SATURATION to the largest
+//     finite magnitude - the reference's `OType(in * scale)` through CUDA's
+//     satfinite conversion (ref common/transpose/cast_transpose.cu:162-165,
+//     common/util/ptx.cuh:973,993);
+//   * amax = max |float(in)| with maxNum semantics (a NaN operand is ignored),
+//     ref cast_transpose.cu:164-165;
+//   * scale_inv = correctly rounded 1/scale (ref common/utils.cuh:950).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace te {
+
+constexpr int kWave = 64;
+
+__host__ __device__ __forceinline__ size_t ceil_div_dev(size_t a, size_t b) { return (a + b - 1) / b; }
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ input widening
+struct bf16_t {
+  uint16_t bits;
+};
+struct f16_t {
+  _Float16 v;
+};
+
+__device__ __forceinline__ float widen(float x) { return x; }
+__device__ __forceinline__ float widen(bf16_t x) { return __uint_as_float(static_cast<uint32_t>(x.bits) << 16); }
+__device__ __forceinline__ float widen(f16_t x) { return static_cast<float>(x.v); }
+
+// fp32 -> bf16 / fp16, round-to-nearest-even, NaN stays NaN (plain casts lower to
+// v_cvt_pk_bf16_f32 / v_cvt_f16_f32 on gfx950).
+__device__ __forceinline__ void narrow(float x, float &out) { out = x; }
+__device__ __forceinline__ void narrow(float x, bf16_t &out) {
+  __bf16 b = static_cast<__bf16>(x);
+  out.bits = __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ void narrow(float x, f16_t &out) { out.v = static_cast<_Float16>(x); }
+
+// ------------------------------------------------------------------ FP8 conversion
+enum class Fp8 { E4M3, E5M2 };
+
+template <Fp8 F>
+struct Fp8Traits;
+template <>
+struct Fp8Traits<Fp8::E4M3> {
+  static constexpr float max_finite = 448.f;
+};
+template <>
+struct Fp8Traits<Fp8::E5M2> {
+  static constexpr float max_finite = 57344.f;
+};
+
+// Clamp to the finite range but let NaN through (v_med3 / v_max would turn a NaN into a
+// finite bound, so the NaN test is explicit: the compare is false for NaN).
+template <Fp8 F>
+__device__ __forceinline__ float sat_finite(float x) {
+  constexpr float m = Fp8Traits<F>::max_finite;
+  return (__builtin_fabsf(x) > m) ? __builtin_copysignf(m, x) : x;
+}
+
+// Two floats -> two FP8 bytes placed in the low (hi=false) or high (hi=true) half of
+// `old`; the other half of `old` is preserved.  Hardware RNE conversion.
+template <Fp8 F, bool HI>
+__device__ __forceinline__ uint32_t cvt_pk_fp8(float a, float b, uint32_t old) {
+  a = sat_finite<F>(a);
+  b = sat_finite<F>(b);
+  if constexpr (F == Fp8::E4M3) {
+    return static_cast<uint32_t>(__builtin_amdgcn_cvt_pk_fp8_f32(a, b, static_cast<int>(old), HI));
+  } else {
+    return static_cast<uint32_t>(__builtin_amdgcn_cvt_pk_bf8_f32(a, b, static_cast<int>(old), HI));
+  }
+}
+
+// Four floats -> one dword of four FP8 bytes (byte i = value i).
+template <Fp8 F>
+__device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
+  uint32_t r = cvt_pk_fp8<F, false>(a, b, 0u);
+  return cvt_pk_fp8<F, true>(c, d, r);
+}
+
+template <Fp8 F>
+__device__ __forceinline__ uint8_t cvt1_fp8(float a) {
+  return static_cast<uint8_t>(cvt_pk_fp8<F, false>(a, a, 0u) & 0xFFu);
+}
+
+// FP8 byte -> float (hardware, exact).
+template <Fp8 F>
+__device__ __forceinline__ float fp8_to_float(uint32_t packed, int byte_idx) {
+  // The byte selector of the builtin must be a constant: switch on it.
+  if constexpr (F == Fp8::E4M3) {
+    switch (byte_idx) {
+      case 0: return __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(packed), 0);
+      case 1: return __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(packed), 1);
+      case 2: return __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(packed), 2);
+      default: return __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(packed), 3);
+    }
+  } else {
+    switch (byte_idx) {
+      case 0: return __builtin_amdgcn_cvt_f32_bf8(static_cast<int>(packed), 0);
+      case 1: return __builtin_amdgcn_cvt_f32_bf8(static_cast<int>(packed), 1);
+      case 2: return __builtin_amdgcn_cvt_f32_bf8(static_cast<int>(packed), 2);
+      default: return __builtin_amdgcn_cvt_f32_bf8(static_cast<int>(packed), 3);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ e8m0 block scales
+// float -> e8m0 exponent, rounding the VALUE up to the next power of two
+// (ref common/util/ptx.cuh:386-417, host twin tests/cpp/test_common.h:480-500).
+__device__ __forceinline__ uint8_t float_to_e8m0(float v) {
+  const uint32_t u = __float_as_uint(v);
+  if (v != v) return 0xFF;
+  if ((u & 0x7FFFFFFFu) == 0x7F800000u) return 0xFE;
+  if (v == 0.0f) return 0x00;
+  uint32_t e = (u >> 23) & 0xFFu;
+  const uint32_t m = u & 0x7FFFFFu;
+  if ((m > 0 && e != 0xFE) && !(e == 0 && m <= 0x400000u)) ++e;
+  return static_cast<uint8_t>(e);
+}
+
+// 2^(127 - e) as a float (ref ptx.cuh:356-364, test_common.h:502-513).
+__device__ __forceinline__ float e8m0_rcp(uint8_t e) {
+  uint32_t bits;
+  if (e == 255) {
+    bits = 0x7FFFFFFFu;
+  } else if (e == 254) {
+    bits = 0x00400000u;
+  } else {
+    bits = static_cast<uint32_t>(254 - e) << 23;
+  }
+  return __uint_as_float(bits);
+}
+
+// 2^(e - 127) for dequantisation, built the way the reference does (exponent field only,
+// ref common/util/ptx.cuh:382-384): e = 0 reads as 0.0, e = 255 as +inf.
+__device__ __forceinline__ float e8m0_to_float(uint8_t e) {
+  return __uint_as_float(static_cast<uint32_t>(e) << 23);
+}
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Max over a workgroup of NWAVES waves; result valid in thread 0.  `scratch` holds NWAVES floats.
+template <int NWAVES>
+__device__ __forceinline__ float block_max(float v, float *scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) v = fmaxf(v, scratch[w]);
+  }
+  return v;
+}
+
+// amax values are >= 0, so their fp32 bit patterns order like unsigned ints
+// (ref common/utils.cuh:935: int-punned atomicMax).
+__device__ __forceinline__ void atomic_max_nonneg(float *addr, float v) {
+  atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}
+
+// ------------------------------------------------------------------ byte shuffles
+// v_perm_b32: result byte i = byte sel[i] of the 64-bit value {hi:lo} (0-3 -> lo, 4-7 -> hi).
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+  return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+// In-register transpose of a 4x4 byte block: r[i] holds row i (byte j = column j);
+// on return r[j] holds column j (byte i = row i).
+__device__ __forceinline__ void transpose4x4_bytes(uint32_t &r0, uint32_t &r1, uint32_t &r2, uint32_t &r3) {
+  const uint32_t t0 = perm(r1, r0, 0x05010400u);  // r0.b0 r1.b0 r0.b1 r1.b1
+  const uint32_t t1 = perm(r1, r0, 0x07030602u);  // r0.b2 r1.b2 r0.b3 r1.b3
+  const uint32_t t2 = perm(r3, r2, 0x05010400u);
+  const uint32_t t3 = perm(r3, r2, 0x07030602u);
+  r0 = perm(t2, t0, 0x05040100u);
+  r1 = perm(t2, t0, 0x07060302u);
+  r2 = perm(t3, t1, 0x05040100u);
+  r3 = perm(t3, t1, 0x07060302u);
+}
+
+__device__ __forceinline__ bool noop_set(const float *noop) { return noop != nullptr && noop[0] == 1.0f; }
+
+}  // namespace te

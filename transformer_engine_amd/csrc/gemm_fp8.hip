@@ -1,0 +1,592 @@
+// Scaled FP8 / MXFP8 GEMM on CDNA4 matrix cores (gfx950).  No BLAS library.
+//
+// Replaces: ref common/gemm/cublaslt_gemm.cu:102-307 (operand canonicalisation),
+//           :315-799 (cublas_gemm), :803-968 (C entry points), :970-1060 (multi-tensor).
+//
+// Problem after canonicalisation ("TN everywhere", see nvte_is_non_tn_fp8_gemm_supported):
+//     D[i][j] = alpha * sP * sQ * sum_k P[i][k] * Q[j][k]  (+ beta * D[i][j]) (+ bias[j])
+// with P = the reference's operand B as an [n, k] K-contiguous byte matrix,
+//      Q = the reference's operand A as an [m, k] K-contiguous byte matrix,
+//      D row-major [n, m] (ld = m), fp32 accumulation.
+// MXFP8: sP / sQ are e8m0 bytes per (row, 32-element K block) applied by the
+// block-scaled MFMA itself.
+//
+// Kernel (v1, "2-phase"): 256x256 output tile per 512-thread workgroup (8 waves as
+// 2 x 4, each 128 x 64 = 4 x 2 MFMA tiles of 32x32), K step 128 bytes, LDS double
+// buffer 2 x (32 KiB P + 32 KiB Q) filled by buffer_load ... lds (LDS-DMA, 16 B per
+// lane), v_mfma_[scale_]f32_32x32x64_f8f6f4 (the rate-doubled FP8 path: 64 K per
+// instruction).  The LDS image is lane-linear as LDS-DMA requires; bank conflicts of
+// the ds_read_b128 fragment reads are removed by XOR-ing the 16-byte chunk index with
+// ((row >> 1) & 7) on the SOURCE address and on the read address.  Out-of-range rows
+// and the K tail are zero-filled by the buffer descriptor's range check, so any n, m
+// and any K % 16 == 0 run through the same kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <type_traits>
+
+#include "common.h"
+#include "device_utils.h"
+#include "transformer_engine/gemm.h"
+#include "transformer_engine/multi_stream.h"
+
+namespace te {
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 256;   // tile rows   (index i, rows of P)
+constexpr int BN = 256;   // tile cols   (index j, rows of Q)
+constexpr int BK = 128;   // bytes of K per stage
+constexpr int kThreads = 512;
+constexpr int kStageBytes = (BM + BN) * BK;  // 64 KiB
+constexpr unsigned kOOB = 0x80000000u;
+
+struct GemmArgs {
+  const uint8_t *P;   // [n, k]
+  const uint8_t *Q;   // [m, k]
+  void *D;            // [n, m]
+  const void *bias;   // [m] or null
+  const float *sP;    // per-tensor scale_inv (device) or null
+  const float *sQ;
+  const uint8_t *eP;  // MX scales for P rows
+  const uint8_t *eQ;
+  unsigned n, m, k;
+  unsigned ldd;
+  unsigned eP_stride, eQ_stride;  // compact layout row stride (bytes)
+  unsigned eP_swz, eQ_swz;        // 1 = GEMM-swizzled 128x4 tiles
+  float alpha, beta;
+  int d_dtype;     // NVTEDType of D
+  int bias_dtype;  // NVTEDType of bias
+  unsigned tiles_j;  // number of tile columns
+  unsigned ntiles;
+};
+
+// XCD-aware, bijective remap of the flat workgroup id: workgroups that share an XCD
+// (id % 8) get a contiguous run of tiles; inside a run tiles are walked in groups of
+// GROUP_I tile rows so that co-resident workgroups share P and Q panels in L2.
+__device__ __forceinline__ void tile_of(unsigned wg, unsigned ntiles, unsigned tiles_i,
+                                        unsigned tiles_j, unsigned &ti, unsigned &tj) {
+  const unsigned q = ntiles / 8, r = ntiles % 8, xcd = wg % 8, local = wg / 8;
+  const unsigned lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  constexpr unsigned GROUP_I = 8;
+  const unsigned per_group = GROUP_I * tiles_j;
+  const unsigned g = lin / per_group;
+  const unsigned first_i = g * GROUP_I;
+  const unsigned gsz = min(tiles_i - first_i, GROUP_I);
+  const unsigned in_g = lin % per_group;
+  ti = first_i + in_g % gsz;
+  tj = in_g / gsz;
+}
+
+template <typename T>
+__device__ __forceinline__ float load_as_float(const void *p, size_t idx);
+template <>
+__device__ __forceinline__ float load_as_float<float>(const void *p, size_t idx) {
+  return static_cast<const float *>(p)[idx];
+}
+template <>
+__device__ __forceinline__ float load_as_float<bf16_t>(const void *p, size_t idx) {
+  return widen(static_cast<const bf16_t *>(p)[idx]);
+}
+template <>
+__device__ __forceinline__ float load_as_float<f16_t>(const void *p, size_t idx) {
+  return widen(static_cast<const f16_t *>(p)[idx]);
+}
+
+__device__ __forceinline__ float load_any(const void *p, size_t idx, int dtype) {
+  switch (dtype) {
+    case kNVTEFloat32: return load_as_float<float>(p, idx);
+    case kNVTEBFloat16: return load_as_float<bf16_t>(p, idx);
+    default: return load_as_float<f16_t>(p, idx);
+  }
+}
+
+// Byte offset of the MX scale dword (4 consecutive K blocks) of `row` for K-stage 0; the
+// per-stage increment is 4 (compact layout) or 512 (swizzled 128x4 tiles).
+__device__ __forceinline__ unsigned scale_row_offset(unsigned row, unsigned nrows, unsigned stride,
+                                                     unsigned swz) {
+  row = min(row, nrows - 1);
+  if (swz) {
+    const unsigned tiles_x = stride / 4;
+    return (row / 128) * tiles_x * 512 + (row % 32) * 16 + ((row % 128) / 32) * 4;
+  }
+  return row * stride;
+}
+
+template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX>
+__global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wi = wave >> 2, wj = wave & 3u;
+
+  const unsigned tiles_i = (a.n + BM - 1) / BM;
+  unsigned ti, tj;
+  tile_of(blockIdx.x, a.ntiles, tiles_i, a.tiles_j, ti, tj);
+  const unsigned i0 = ti * BM, j0 = tj * BN;
+
+  // Buffer descriptors that cover exactly this tile's rows: rows past the matrix end and
+  // explicit kOOB offsets read as zero.
+  const unsigned rows_p = min(a.n - i0, static_cast<unsigned>(BM));
+  const unsigned rows_q = min(a.m - j0, static_cast<unsigned>(BN));
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(a.P) + static_cast<size_t>(i0) * a.k, 0, rows_p * a.k, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(a.Q) + static_cast<size_t>(j0) * a.k, 0, rows_q * a.k, 0x00020000);
+
+  // staging geometry: wave-instruction q of this wave fills rows (wave*4+q)*8 .. +7
+  const unsigned st_row_in8 = lane >> 3;   // 0..7
+  const unsigned st_chunkpos = lane & 7u;  // LDS chunk slot this lane writes
+  unsigned st_off[4];                      // byte offset of (row, source chunk) without k0
+  unsigned st_chunk_k[4];                  // source chunk * 16
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned r = (wave * 4 + q) * 8 + st_row_in8;
+    const unsigned c = st_chunkpos ^ ((r >> 1) & 7u);
+    st_off[q] = r * a.k + c * 16;
+    st_chunk_k[q] = c * 16;
+  }
+
+  auto stage = [&](unsigned buf, unsigned k0) {
+    uint8_t *base = lds + buf * kStageBytes;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool k_ok = k0 + st_chunk_k[q] < a.k;
+      const unsigned off = k_ok ? st_off[q] + k0 : kOOB;
+      typedef __attribute__((address_space(3))) uint8_t lds_u8;
+      lds_u8 *dst_p = (lds_u8 *)(base + (wave * 4 + q) * 1024);
+      lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, off, 0, 0, 0);
+    }
+  };
+
+  // fragment read geometry
+  const unsigned fr_row = lane & 31u;
+  const unsigned fr_half = lane >> 5;  // which 32-byte K block of the 64-byte MFMA step
+  unsigned rdP[4], rdQ[2];             // row byte offsets inside the P / Q images
+  unsigned swP[4], swQ[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const unsigned r = wi * 128 + mi * 32 + fr_row;
+    rdP[mi] = r * BK;
+    swP[mi] = (r >> 1) & 7u;
+  }
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj) {
+    const unsigned r = wj * 64 + nj * 32 + fr_row;
+    rdQ[nj] = BM * BK + r * BK;
+    swQ[nj] = (r >> 1) & 7u;
+  }
+
+  v16f acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+  const unsigned nk = (a.k + BK - 1) / BK;
+
+  // MX scales: one dword = the 4 K blocks of a stage for one row.  scX hold the current
+  // stage, nxX the next one (loaded while the current stage is being multiplied).
+  uint32_t scP[4] = {0, 0, 0, 0}, scQ[2] = {0, 0};
+  uint32_t nxP[4] = {0, 0, 0, 0}, nxQ[2] = {0, 0};
+  unsigned soP[4] = {0, 0, 0, 0}, soQ[2] = {0, 0};
+  __amdgpu_buffer_rsrc_t re_p, re_q;
+  unsigned sstepP = 0, sstepQ = 0;
+  if constexpr (MX) {
+    re_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eP), 0, 0xFFFFFFFFu, 0x00020000);
+    re_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eQ), 0, 0xFFFFFFFFu, 0x00020000);
+    sstepP = a.eP_swz ? 512u : 4u;
+    sstepQ = a.eQ_swz ? 512u : 4u;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+      soP[mi] = scale_row_offset(i0 + wi * 128 + mi * 32 + fr_row, a.n, a.eP_stride, a.eP_swz);
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+      soQ[nj] = scale_row_offset(j0 + wj * 64 + nj * 32 + fr_row, a.m, a.eQ_stride, a.eQ_swz);
+  }
+  auto load_scales = [&](unsigned kt) {
+    if constexpr (MX) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        nxP[mi] = __builtin_amdgcn_raw_buffer_load_b32(re_p, soP[mi] + kt * sstepP, 0, 0);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+        nxQ[nj] = __builtin_amdgcn_raw_buffer_load_b32(re_q, soQ[nj] + kt * sstepQ, 0, 0);
+    }
+  };
+  // K blocks past the end of K carry whatever the padded scale buffer holds: force 2^0 there
+  // (their payload bytes are zero-filled) and pre-shift so that opsel 0 / 2 pick this lane's block.
+  auto commit_scales = [&](unsigned kt) {
+    if constexpr (MX) {
+      const unsigned valid = min(4u, (a.k - kt * BK + 31) / 32);
+      const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * valid)) - 1u);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) scP[mi] = ((nxP[mi] & keep) | (0x7F7F7F7Fu & ~keep)) >> (8 * fr_half);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) scQ[nj] = ((nxQ[nj] & keep) | (0x7F7F7F7Fu & ~keep)) >> (8 * fr_half);
+    }
+  };
+
+  stage(0, 0);
+  load_scales(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  commit_scales(0);
+  __syncthreads();
+
+  for (unsigned kt = 0; kt < nk; ++kt) {
+    const unsigned cur = kt & 1u;
+    if (kt + 1 < nk) stage(cur ^ 1u, (kt + 1) * BK);
+    if (kt + 1 < nk) load_scales(kt + 1);
+    const uint8_t *img = lds + cur * kStageBytes;
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // Operand register map of v_mfma_*_32x32x64_f8f6f4 (measured on gfx950): a lane's first
+      // 16 bytes are K = 16*half + [0,16), its last 16 bytes K = 32 + 16*half + [0,16); the
+      // 32-element block b = {both halves' bytes 16b..16b+15} takes its e8m0 scale from lane half b.
+      const unsigned c0 = ks * 4 + fr_half;
+      v8i fa[4], fb[2];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + rdP[mi] + ((c0 ^ swP[mi]) << 4));
+        const u32x4 hi = *reinterpret_cast<const u32x4 *>(img + rdP[mi] + (((c0 + 2) ^ swP[mi]) << 4));
+        fa[mi] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + rdQ[nj] + ((c0 ^ swQ[nj]) << 4));
+        const u32x4 hi = *reinterpret_cast<const u32x4 *>(img + rdQ[nj] + (((c0 + 2) ^ swQ[nj]) << 4));
+        fb[nj] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          if constexpr (MX) {
+            if (ks == 0) {
+              acc[mi][nj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                  fa[mi], fb[nj], acc[mi][nj], FA, FB, 0, (int)scP[mi], 0, (int)scQ[nj]);
+            } else {
+              acc[mi][nj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                  fa[mi], fb[nj], acc[mi][nj], FA, FB, 2, (int)scP[mi], 2, (int)scQ[nj]);
+            }
+          } else {
+            acc[mi][nj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                fa[mi], fb[nj], acc[mi][nj], FA, FB, 0, 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) commit_scales(kt + 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------ epilogue
+  float mult = a.alpha;
+  if constexpr (!MX) {
+    if (a.sP) mult *= *a.sP;
+    if (a.sQ) mult *= *a.sQ;
+  }
+  auto epilogue = [&](auto *dptr, auto with_c) {
+    using OT = std::remove_pointer_t<decltype(dptr)>;
+    constexpr bool WITH_C = decltype(with_c)::value;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const unsigned j = j0 + wj * 64 + nj * 32 + (lane & 31u);
+      if (j >= a.m) continue;
+      const float bias = a.bias ? load_any(a.bias, j, a.bias_dtype) : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const unsigned ib = i0 + wi * 128 + mi * 32 + 4 * (lane >> 5);
+        OT *col = dptr + static_cast<size_t>(ib) * a.ldd + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned di = (r & 3) + 8 * (r >> 2);
+          if (ib + di >= a.n) continue;
+          OT *p = col + static_cast<size_t>(di) * a.ldd;
+          float v = acc[mi][nj][r] * mult;
+          if constexpr (WITH_C) v += a.beta * widen(*p);
+          v += bias;
+          narrow(v, *p);
+        }
+      }
+    }
+  };
+  const bool with_c = a.beta != 0.f;
+  switch (a.d_dtype) {
+    case kNVTEFloat32:
+      with_c ? epilogue(static_cast<float *>(a.D), std::true_type{}) : epilogue(static_cast<float *>(a.D), std::false_type{});
+      break;
+    case kNVTEBFloat16:
+      with_c ? epilogue(static_cast<bf16_t *>(a.D), std::true_type{}) : epilogue(static_cast<bf16_t *>(a.D), std::false_type{});
+      break;
+    default:
+      with_c ? epilogue(static_cast<f16_t *>(a.D), std::true_type{}) : epilogue(static_cast<f16_t *>(a.D), std::false_type{});
+      break;
+  }
+}
+
+template <bool MX>
+void launch_by_format(int fa, int fb, const GemmArgs &args, hipStream_t stream) {
+  const dim3 grid(args.ntiles), block(kThreads);
+#define TE_GEMM_CASE(A_, B_)                                                                       \
+  if (fa == A_ && fb == B_) {                                                                      \
+    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX>), grid, block, 0, stream, args);              \
+    NVTE_CHECK_HIP(hipGetLastError());                                                             \
+    return;                                                                                        \
+  }
+  TE_GEMM_CASE(0, 0)
+  TE_GEMM_CASE(0, 1)
+  TE_GEMM_CASE(1, 0)
+  TE_GEMM_CASE(1, 1)
+#undef TE_GEMM_CASE
+  NVTE_ERROR("unsupported FP8 format combination");
+}
+
+int fmt_of(DType t) { return t == kNVTEFloat8E4M3 ? 0 : 1; }
+
+// One operand after canonicalisation: a K-contiguous byte matrix [rows, k].
+struct Operand {
+  const uint8_t *data = nullptr;
+  DType dtype = kNVTEByte;
+  const void *scale_inv = nullptr;
+  unsigned scale_stride = 0;
+  bool swizzled = false;
+};
+
+}  // namespace
+
+// D = alpha * op(A) op(B) + beta * D  (+bias).  Names follow the reference's cublas_gemm.
+void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, const Tensor *pre_gelu,
+               bool transa, bool transb, bool grad, float alpha, float beta, hipStream_t stream) {
+  const auto [A0, A1] = A.flat2d();
+  const auto [B0, B1] = B.flat2d();
+  const size_t m = transa ? A0 : A1;
+  const size_t k = transa ? A1 : A0;
+  const size_t n = transb ? B1 : B0;
+  NVTE_CHECK((transb ? B0 : B1) == k, "GEMM inputs have incompatible dimensions (A is ", A0, "x", A1,
+             ", B is ", B0, "x", B1, ")");
+  if (m == 0 || n == 0) return;
+  NVTE_CHECK(k > 0, "GEMM with k == 0 is not supported");
+  NVTE_CHECK(A.scaling_mode == B.scaling_mode,
+             "Inputs A and B to GEMM need to have compatible scaling modes, but got A.scaling_mode = ",
+             scaling_mode_name(A.scaling_mode), ", B.scaling_mode = ", scaling_mode_name(B.scaling_mode));
+  NVTE_CHECK(A.has_data() || A.has_columnwise_data(), "Input A does not hold any data!");
+  NVTE_CHECK(B.has_data() || B.has_columnwise_data(), "Input B does not hold any data!");
+  NVTE_CHECK(pre_gelu == nullptr || pre_gelu->data.ptr == nullptr,
+             "GELU / dGELU GEMM epilogues are not implemented in this library (out of the Linear hot path)");
+  NVTE_CHECK(D.data.ptr != nullptr, "Output D is not allocated");
+  NVTE_CHECK(D.data.numel() == m * n, "Output D has wrong size (expected ", n, "x", m, ", got ",
+             D.data.shape, ")");
+  NVTE_CHECK(D.data.dtype == kNVTEFloat32 || D.data.dtype == kNVTEBFloat16 || D.data.dtype == kNVTEFloat16,
+             "GEMM output dtype ", dtype_name(D.data.dtype), " is not supported (FP32/BF16/FP16 only)");
+  const bool has_bias = bias != nullptr && bias->data.ptr != nullptr;
+  NVTE_CHECK(!(has_bias && grad), "bgrad GEMM epilogue is not implemented: use nvte_quantize_dbias / "
+                                  "nvte_cast_transpose_dbias for the bias gradient");
+  if (has_bias) {
+    NVTE_CHECK(bias->data.numel() == m, "Bias has wrong size (expected ", m, ", got ", bias->data.numel(), ")");
+    NVTE_CHECK(is_high_precision(bias->data.dtype), "Bias dtype must be FP32/BF16/FP16");
+  }
+
+  Operand opA, opB;  // opA rows = m (reference A), opB rows = n (reference B)
+  bool mx = false;
+  if (is_tensor_scaling(A.scaling_mode)) {
+    // Per-tensor scaling.  nvte_is_non_tn_fp8_gemm_supported() == 0, so a non-transposed A
+    // (transposed B) is replaced by its pre-transposed "columnwise" copy: every FP8 GEMM is TN.
+    if (transa) {
+      opA.data = static_cast<const uint8_t *>(A.data.ptr);
+      opA.dtype = A.data.dtype;
+      opA.scale_inv = A.scale_inv.ptr;
+      NVTE_CHECK(A.has_data(), "Input A is missing row-wise usage");
+    } else {
+      NVTE_CHECK(A.has_columnwise_data() && is_fp8(A.columnwise_data.dtype),
+                 "Input A is missing column-wise usage");
+      opA.data = static_cast<const uint8_t *>(A.columnwise_data.ptr);
+      opA.dtype = A.columnwise_data.dtype;
+      opA.scale_inv = A.columnwise_scale_inv.ptr;
+    }
+    if (!transb) {
+      opB.data = static_cast<const uint8_t *>(B.data.ptr);
+      opB.dtype = B.data.dtype;
+      opB.scale_inv = B.scale_inv.ptr;
+      NVTE_CHECK(B.has_data(), "Input B is missing row-wise usage");
+    } else {
+      NVTE_CHECK(B.has_columnwise_data() && is_fp8(B.columnwise_data.dtype),
+                 "Input B is missing column-wise usage");
+      opB.data = static_cast<const uint8_t *>(B.columnwise_data.ptr);
+      opB.dtype = B.columnwise_data.dtype;
+      opB.scale_inv = B.columnwise_scale_inv.ptr;
+    }
+    NVTE_CHECK(is_fp8(opA.dtype) && is_fp8(opB.dtype),
+               "This library implements the FP8 GEMM only; got A dtype ", dtype_name(opA.dtype),
+               ", B dtype ", dtype_name(opB.dtype));
+    NVTE_CHECK(opA.scale_inv != nullptr && opB.scale_inv != nullptr,
+               "FP8 input to GEMM requires inverse of scale!");
+    NVTE_CHECK(k % 16 == 0, "Leading dimension requirement on A for FP8 GEMM. Caller must pad.");
+  } else if (is_mxfp8(A.scaling_mode)) {
+    mx = true;
+    // Rowwise data is K-contiguous only for a transposed A / non-transposed B.
+    NVTE_CHECK(transa, "MXFP8 GEMM: non-transposed A (columnwise operand) is not implemented yet");
+    NVTE_CHECK(!transb, "MXFP8 GEMM: transposed B (columnwise operand) is not implemented yet");
+    NVTE_CHECK(A.has_data(), "Input A is missing row-wise usage");
+    NVTE_CHECK(B.has_data(), "Input B is missing row-wise usage");
+    opA.data = static_cast<const uint8_t *>(A.data.ptr);
+    opA.dtype = A.data.dtype;
+    opA.scale_inv = A.scale_inv.ptr;
+    opA.scale_stride = static_cast<unsigned>(A.scale_inv.shape.data[A.scale_inv.shape.ndim - 1]);
+    opA.swizzled = A.with_gemm_swizzled_scales;
+    opB.data = static_cast<const uint8_t *>(B.data.ptr);
+    opB.dtype = B.data.dtype;
+    opB.scale_inv = B.scale_inv.ptr;
+    opB.scale_stride = static_cast<unsigned>(B.scale_inv.shape.data[B.scale_inv.shape.ndim - 1]);
+    opB.swizzled = B.with_gemm_swizzled_scales;
+    NVTE_CHECK(is_fp8(opA.dtype) && is_fp8(opB.dtype), "MXFP8 GEMM needs FP8 payloads");
+    NVTE_CHECK(opA.scale_inv != nullptr && opB.scale_inv != nullptr,
+               "FP8 input to GEMM requires inverse of scale!");
+    NVTE_CHECK(k % 32 == 0, "MXFP8 GEMM requires K to be a multiple of 32, got ", k);
+  } else {
+    NVTE_ERROR("Not implemented scaling modes: ", scaling_mode_name(A.scaling_mode), " and ",
+               scaling_mode_name(B.scaling_mode), ".");
+  }
+  NVTE_CHECK((reinterpret_cast<uintptr_t>(opA.data) & 15u) == 0 &&
+                 (reinterpret_cast<uintptr_t>(opB.data) & 15u) == 0,
+             "FP8 GEMM operands must be 16-byte aligned");
+  NVTE_CHECK(k <= (1u << 23), "K too large for this kernel's 32-bit tile offsets");
+  NVTE_CHECK(n < (1ull << 31) && m < (1ull << 31), "matrix too large");
+
+  (void)device_info();  // throws without a usable GPU
+
+  GemmArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.P = opB.data;
+  g.Q = opA.data;
+  g.D = D.data.ptr;
+  g.bias = has_bias ? bias->data.ptr : nullptr;
+  g.bias_dtype = has_bias ? bias->data.dtype : kNVTEFloat32;
+  if (mx) {
+    g.eP = static_cast<const uint8_t *>(opB.scale_inv);
+    g.eQ = static_cast<const uint8_t *>(opA.scale_inv);
+    g.eP_stride = opB.scale_stride;
+    g.eQ_stride = opA.scale_stride;
+    g.eP_swz = opB.swizzled;
+    g.eQ_swz = opA.swizzled;
+  } else {
+    g.sP = static_cast<const float *>(opB.scale_inv);
+    g.sQ = static_cast<const float *>(opA.scale_inv);
+  }
+  g.n = static_cast<unsigned>(n);
+  g.m = static_cast<unsigned>(m);
+  g.k = static_cast<unsigned>(k);
+  g.ldd = static_cast<unsigned>(m);
+  g.alpha = alpha;
+  g.beta = beta;
+  g.d_dtype = D.data.dtype;
+  g.tiles_j = static_cast<unsigned>(ceil_div(m, BN));
+  g.ntiles = static_cast<unsigned>(ceil_div(n, BM)) * g.tiles_j;
+  if (mx)
+    launch_by_format<true>(fmt_of(opB.dtype), fmt_of(opA.dtype), g, stream);
+  else
+    launch_by_format<false>(fmt_of(opB.dtype), fmt_of(opA.dtype), g, stream);
+}
+
+}  // namespace te
+
+using namespace te;
+
+extern "C" {
+
+void nvte_cublas_handle_init(void) {}
+
+void nvte_cublas_gemm(const NVTETensor A, const NVTETensor B, NVTETensor D, const NVTETensor bias,
+                      NVTETensor pre_gelu_out, bool transa, bool transb, bool grad,
+                      NVTETensor workspace, bool accumulate, bool use_split_accumulator,
+                      int math_sm_count, hipStream_t stream) {
+  api_guard("nvte_cublas_gemm", [&] {
+    (void)workspace; (void)use_split_accumulator; (void)math_sm_count;
+    gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
+              lookup(pre_gelu_out), transa, transb, grad, 1.f, accumulate ? 1.f : 0.f, stream);
+  });
+}
+
+void nvte_cublas_gemm_scaled(const NVTETensor A, const NVTETensor B, NVTETensor D,
+                             const NVTETensor bias, NVTETensor pre_gelu_out, bool transa,
+                             bool transb, bool grad, NVTETensor workspace, float alpha, float beta,
+                             bool use_split_accumulator, int math_sm_count, hipStream_t stream) {
+  api_guard("nvte_cublas_gemm_scaled", [&] {
+    (void)workspace; (void)use_split_accumulator; (void)math_sm_count;
+    gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
+              lookup(pre_gelu_out), transa, transb, grad, alpha, beta, stream);
+  });
+}
+
+void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTETensor A,
+                         const NVTETensor B, const float *beta, const NVTETensor C, NVTETensor D,
+                         NVTETensor workspace, NVTEMatmulConfig config, hipStream_t stream) {
+  api_guard("nvte_cublas_gemm_v2", [&] {
+    (void)workspace;
+    const Tensor &a = *lookup_checked(A);
+    const Tensor &b = *lookup_checked(B);
+    const Tensor *c = lookup_checked(C);
+    Tensor *d = lookup_checked(D);
+    NVTE_CHECK(c == d, "Currently nvte_cublas_gemm_v2 does not support different C and D tensors.");
+    NVTE_CHECK(alpha != nullptr && beta != nullptr, "alpha and beta must be valid host pointers");
+    MatmulConfig cfg;
+    if (config != nullptr) cfg = *static_cast<const MatmulConfig *>(config);
+    const bool grad_epi = cfg.dbias_tensor != nullptr || cfg.with_dgelu_epilogue;
+    if (grad_epi) {
+      NVTE_CHECK(cfg.bias_tensor == nullptr && !cfg.with_gelu_epilogue, "Invalid epilogue (bias=",
+                 cfg.bias_tensor != nullptr, ", dbias=", cfg.dbias_tensor != nullptr,
+                 ", gelu=", cfg.with_gelu_epilogue, ", dgelu=", cfg.with_dgelu_epilogue, ").");
+    }
+    const Tensor *bias_t = nullptr;
+    if (!grad_epi && cfg.bias_tensor != nullptr) bias_t = lookup_checked(cfg.bias_tensor);
+    if (grad_epi && cfg.dbias_tensor != nullptr) bias_t = lookup_checked(cfg.dbias_tensor);
+    const Tensor *aux = nullptr;
+    if (cfg.with_gelu_epilogue || cfg.with_dgelu_epilogue) {
+      NVTE_CHECK(cfg.epilogue_aux_tensor != nullptr, "Requested epilogue without providing aux tensor.");
+      aux = lookup(cfg.epilogue_aux_tensor);
+    }
+    gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, *alpha, *beta, stream);
+  });
+}
+
+void nvte_multi_tensor_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor *D,
+                            const NVTETensor *bias, NVTETensor *pre_gelu_out, const int num_gemms,
+                            bool transa, bool transb, bool grad, NVTETensor *workspace,
+                            bool accumulate, bool use_split_accumulator, int math_sm_count,
+                            hipStream_t stream) {
+  api_guard("nvte_multi_tensor_gemm", [&] {
+    (void)workspace; (void)use_split_accumulator; (void)math_sm_count;
+    if (num_gemms <= 0) return;
+    // Independent GEMMs fanned over the compute-stream pool and joined on `stream`
+    // (ref cublaslt_gemm.cu:970-1023).
+    const int ns = std::min(num_gemms, nvte_get_num_compute_streams());
+    hipEvent_t e0 = nvte_get_compute_stream_event(0);
+    NVTE_CHECK_HIP(hipEventRecord(e0, stream));
+    for (int s = 0; s < ns; ++s) NVTE_CHECK_HIP(hipStreamWaitEvent(nvte_get_compute_stream(s), e0, 0));
+    for (int i = 0; i < num_gemms; ++i) {
+      gemm_impl(*lookup_checked(A[i]), *lookup_checked(B[i]), *lookup_checked(D[i]),
+                bias ? lookup(bias[i]) : nullptr, pre_gelu_out ? lookup(pre_gelu_out[i]) : nullptr,
+                transa, transb, grad, 1.f, accumulate ? 1.f : 0.f,
+                nvte_get_compute_stream(i % nvte_get_num_compute_streams()));
+    }
+    for (int s = 0; s < ns; ++s) {
+      hipEvent_t e = nvte_get_compute_stream_event(s);
+      NVTE_CHECK_HIP(hipEventRecord(e, nvte_get_compute_stream(s)));
+      NVTE_CHECK_HIP(hipStreamWaitEvent(stream, e, 0));
+    }
+  });
+}
+
+}  // extern "C"

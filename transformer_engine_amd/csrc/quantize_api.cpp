@@ -1,0 +1,204 @@
+// C entry points for quantize / cast_transpose / dequantize and their list forms,
+// plus the compute-stream pool.
+//
+// Replaces: ref common/cast/cast.cu:21-89, common/cast/dispatch/quantize.cuh:33-197,
+//           common/transpose/cast_transpose.cu:348-363, multi_cast_transpose.cu:335,
+//           common/util/multi_stream.cpp:22-67.
+#include <mutex>
+
+#include "common.h"
+#include "transformer_engine/cast.h"
+#include "transformer_engine/cast_transpose_noop.h"
+#include "transformer_engine/multi_stream.h"
+#include "transformer_engine/transpose.h"
+
+namespace te {
+
+bool dbias_workspace_query(const Tensor &in, Tensor &workspace);                             // dbias.hip
+void dbias_launch(const Tensor &in, Tensor &dbias, Tensor &workspace, hipStream_t stream);   // dbias.hip
+
+// The OUTPUT tensor's format picks the kernel (ref dispatch/quantize.cuh:63-93).
+void quantize_dispatch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream) {
+  NVTE_CHECK(out.has_data() || out.has_columnwise_data(),
+             "Either rowwise or columnwise output data need to be allocated.");
+  switch (out.scaling_mode) {
+    case NVTE_DELAYED_TENSOR_SCALING:
+      if (out.has_columnwise_data()) {
+        NVTE_CHECK(out.has_data(), "Quantizing in only the columnwise direction not supported yet!");
+        cast_transpose_launch(in, noop, out, stream);
+      } else {
+        cast_rowwise_launch(in, noop, out, stream);
+      }
+      break;
+    case NVTE_MXFP8_1D_SCALING:
+      mxfp8_quantize_launch(in, noop, out, stream);
+      break;
+    default:
+      NVTE_ERROR("Not implemented scaling mode: ", scaling_mode_name(out.scaling_mode), ".");
+  }
+}
+
+namespace {
+
+constexpr int kNumStreams = 4;  // ref multi_stream.cpp:22
+struct StreamPool {
+  hipStream_t s[kNumStreams];
+  hipEvent_t e[kNumStreams];
+  bool ready = false;
+};
+// one pool per device ordinal
+StreamPool &pool() {
+  static std::mutex mu;
+  static StreamPool pools[64];
+  int dev = 0;
+  NVTE_CHECK_HIP(hipGetDevice(&dev));
+  NVTE_CHECK(dev >= 0 && dev < 64, "device ordinal out of range");
+  std::lock_guard<std::mutex> g(mu);
+  StreamPool &p = pools[dev];
+  if (!p.ready) {
+    for (int i = 0; i < kNumStreams; ++i) {
+      NVTE_CHECK_HIP(hipStreamCreateWithPriority(&p.s[i], hipStreamNonBlocking, -1));
+      NVTE_CHECK_HIP(hipEventCreateWithFlags(&p.e[i], hipEventDisableTiming));
+    }
+    p.ready = true;
+  }
+  return p;
+}
+
+void with_config(const NVTETensor input, NVTETensor output, const QuantConfig *cfg,
+                 hipStream_t stream) {
+  const Tensor &in = *lookup_checked(input);
+  Tensor &out = *lookup_checked(output);
+  if (cfg != nullptr && cfg->stochastic_rounding) {
+    NVTE_CHECK(out.scaling_mode == NVTE_NVFP4_1D_SCALING,
+               "Stochastic rounding is only supported for NVFP4 quantization.");
+  }
+  quantize_dispatch(in, noop_ptr_of(cfg), out, stream);
+}
+
+}  // namespace
+}  // namespace te
+
+using namespace te;
+
+extern "C" {
+
+void nvte_quantize(const NVTETensor input, NVTETensor output, hipStream_t stream) {
+  api_guard("nvte_quantize", [&] { with_config(input, output, nullptr, stream); });
+}
+
+void nvte_quantize_noop(const NVTETensor input, NVTETensor output, NVTETensor noop,
+                        hipStream_t stream) {
+  api_guard("nvte_quantize_noop", [&] {
+    QuantConfig cfg;
+    cfg.noop_tensor = noop;
+    with_config(input, output, &cfg, stream);
+  });
+}
+
+void nvte_quantize_v2(const NVTETensor input, NVTETensor output,
+                      const NVTEQuantizationConfig quant_config, hipStream_t stream) {
+  api_guard("nvte_quantize_v2", [&] {
+    with_config(input, output, static_cast<const QuantConfig *>(quant_config), stream);
+  });
+}
+
+void nvte_quantize_dbias(const NVTETensor input, NVTETensor output, NVTETensor dbias,
+                         NVTETensor workspace, hipStream_t stream) {
+  api_guard("nvte_quantize_dbias", [&] {
+    const Tensor &in = *lookup_checked(input);
+    Tensor &out = *lookup_checked(output);
+    Tensor &db = *lookup_checked(dbias);
+    Tensor &ws = *lookup_checked(workspace);
+    check_input(in, "cast_input");
+    if (dbias_workspace_query(in, ws)) return;
+    quantize_dispatch(in, nullptr, out, stream);
+    dbias_launch(in, db, ws, stream);
+  });
+}
+
+void nvte_dequantize(const NVTETensor input, NVTETensor output, hipStream_t stream) {
+  api_guard("nvte_dequantize",
+            [&] { dequantize_launch(*lookup_checked(input), *lookup_checked(output), stream); });
+}
+
+void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
+                                const NVTEQuantizationConfig quant_config, const size_t num_tensors,
+                                hipStream_t stream) {
+  api_guard("nvte_multi_tensor_quantize", [&] {
+    if (num_tensors == 0) return;
+    // Fork over the compute-stream pool, join back on `stream` (ref cast.cu:65-88).
+    StreamPool &p = pool();
+    const int used = static_cast<int>(std::min<size_t>(num_tensors, kNumStreams));
+    NVTE_CHECK_HIP(hipEventRecord(p.e[0], stream));
+    for (int s = 0; s < used; ++s) NVTE_CHECK_HIP(hipStreamWaitEvent(p.s[s], p.e[0], 0));
+    for (size_t i = 0; i < num_tensors; ++i) {
+      with_config(inputs[i], outputs[i], static_cast<const QuantConfig *>(quant_config),
+                  p.s[i % kNumStreams]);
+    }
+    for (int s = 0; s < used; ++s) {
+      NVTE_CHECK_HIP(hipEventRecord(p.e[s], p.s[s]));
+      NVTE_CHECK_HIP(hipStreamWaitEvent(stream, p.e[s], 0));
+    }
+  });
+}
+
+void nvte_cast_transpose(const NVTETensor input, NVTETensor output, hipStream_t stream) {
+  api_guard("nvte_cast_transpose", [&] {
+    cast_transpose_launch(*lookup_checked(input), nullptr, *lookup_checked(output), stream);
+  });
+}
+
+void nvte_cast_transpose_with_noop(const NVTETensor input, const NVTETensor noop, NVTETensor output,
+                                   hipStream_t stream) {
+  api_guard("nvte_cast_transpose_with_noop", [&] {
+    const Tensor &n = *lookup_checked(noop);
+    check_noop(n, "cast_transpose_noop");
+    cast_transpose_launch(*lookup_checked(input), static_cast<const float *>(n.data.ptr),
+                          *lookup_checked(output), stream);
+  });
+}
+
+void nvte_cast_transpose_dbias(const NVTETensor input, NVTETensor output, NVTETensor dbias,
+                               NVTETensor workspace, hipStream_t stream) {
+  api_guard("nvte_cast_transpose_dbias", [&] {
+    const Tensor &in = *lookup_checked(input);
+    Tensor &out = *lookup_checked(output);
+    Tensor &db = *lookup_checked(dbias);
+    Tensor &ws = *lookup_checked(workspace);
+    check_input(in, "cast_transpose_input");
+    if (dbias_workspace_query(in, ws)) return;
+    cast_transpose_launch(in, nullptr, out, stream);
+    dbias_launch(in, db, ws, stream);
+  });
+}
+
+void nvte_multi_cast_transpose(size_t num_tensors, const NVTETensor *input_list,
+                               NVTETensor *output_list, hipStream_t stream) {
+  api_guard("nvte_multi_cast_transpose", [&] {
+    for (size_t i = 0; i < num_tensors; ++i) {
+      cast_transpose_launch(*lookup_checked(input_list[i]), nullptr, *lookup_checked(output_list[i]),
+                            stream);
+    }
+  });
+}
+
+int nvte_get_num_compute_streams(void) { return kNumStreams; }
+
+hipStream_t nvte_get_compute_stream(const int idx) {
+  return api_guard("nvte_get_compute_stream", [&]() -> hipStream_t {
+    NVTE_CHECK(0 <= idx && idx < kNumStreams, "Invalid compute stream (requested idx ", idx,
+               ", but there are ", kNumStreams, " streams)");
+    return pool().s[idx];
+  });
+}
+
+hipEvent_t nvte_get_compute_stream_event(const int idx) {
+  return api_guard("nvte_get_compute_stream_event", [&]() -> hipEvent_t {
+    NVTE_CHECK(0 <= idx && idx < kNumStreams, "Invalid compute stream (requested idx ", idx,
+               ", but there are ", kNumStreams, " streams)");
+    return pool().e[idx];
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,697 @@
+// Tensor-handle arena, descriptor getters/setters, config objects, validators,
+// error-mode plumbing.  Host only.
+//
+// Behavioural contract follows the reference's common/transformer_engine.cpp
+// (arena :396-498, getters :602-726, set/get param :728-975, quantization config
+// :979-1123, validators :44-259).  The arena itself is designed differently: slots
+// live in fixed 1024-entry chunks that are never moved, so a lookup needs no lock
+// and no reserve-the-world vector; create/destroy take one mutex.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "common.h"
+#include "transformer_engine/amd_ext.h"
+#include "transformer_engine/gemm.h"
+
+namespace te {
+
+const char *dtype_name(DType t) {
+  switch (t) {
+    case kNVTEByte: return "Byte";
+    case kNVTEInt16: return "Int16";
+    case kNVTEInt32: return "Int32";
+    case kNVTEInt64: return "Int64";
+    case kNVTEFloat32: return "Float32";
+    case kNVTEFloat16: return "Float16";
+    case kNVTEBFloat16: return "BFloat16";
+    case kNVTEFloat8E4M3: return "Float8E4M3";
+    case kNVTEFloat8E5M2: return "Float8E5M2";
+    case kNVTEFloat8E8M0: return "Float8E8M0";
+    case kNVTEFloat4E2M1: return "Float4E2M1";
+    default: return "Invalid";
+  }
+}
+
+const char *scaling_mode_name(NVTEScalingMode m) {
+  switch (m) {
+    case NVTE_DELAYED_TENSOR_SCALING: return "NVTE_DELAYED_TENSOR_SCALING";
+    case NVTE_MXFP8_1D_SCALING: return "NVTE_MXFP8_1D_SCALING";
+    case NVTE_BLOCK_SCALING_1D: return "NVTE_BLOCK_SCALING_1D";
+    case NVTE_BLOCK_SCALING_2D: return "NVTE_BLOCK_SCALING_2D";
+    case NVTE_NVFP4_1D_SCALING: return "NVTE_NVFP4_1D_SCALING";
+    case NVTE_INVALID_SCALING: return "NVTE_INVALID_SCALING";
+    default: return "UNKNOWN";
+  }
+}
+
+// ------------------------------------------------------------------ arena
+namespace {
+
+constexpr size_t kChunk = 1024;
+constexpr size_t kMaxChunks = 4096;  // 4 Mi live descriptors; far above any real use
+
+class Arena {
+ public:
+  static Arena &get() {
+    static Arena a;
+    return a;
+  }
+
+  void create(NVTEScalingMode mode, NVTETensor *out, size_t n) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t slot;
+      if (!free_.empty()) {
+        slot = free_.back();
+        free_.pop_back();
+      } else {
+        slot = static_cast<uint32_t>(high_water_.load(std::memory_order_relaxed));
+        const size_t c = slot / kChunk;
+        NVTE_CHECK(c < kMaxChunks, "Cannot allocate ", n,
+                   " new NVTETensors. Maximum number of tensors reached: ", kChunk * kMaxChunks,
+                   ". There is probably a memory leak in your application.");
+        if (!chunks_[c].load(std::memory_order_acquire)) {
+          chunks_[c].store(new Tensor[kChunk], std::memory_order_release);
+        }
+        high_water_.store(slot + 1, std::memory_order_release);
+      }
+      Tensor &t = at(slot);
+      t.reset(mode);
+      t.slot = slot;
+      t.live = true;
+      out[i] = reinterpret_cast<NVTETensor>(static_cast<uintptr_t>(slot) + 1);
+    }
+  }
+
+  void destroy(NVTETensor *hs, size_t n) {
+    std::lock_guard<std::mutex> g(mu_);
+    for (size_t i = 0; i < n; ++i) {
+      const uintptr_t h = reinterpret_cast<uintptr_t>(hs[i]);
+      if (h == 0) continue;
+      NVTE_CHECK(h <= high_water_.load(std::memory_order_relaxed), "Invalid tensor.");
+      Tensor &t = at(static_cast<uint32_t>(h - 1));
+      if (!t.live) continue;  // double destroy is a no-op rather than a corrupt free list
+      t.reset(NVTE_DELAYED_TENSOR_SCALING);
+      t.live = false;
+      free_.push_back(static_cast<uint32_t>(h - 1));
+    }
+  }
+
+  Tensor *find(NVTETensor hnd) {
+    const uintptr_t h = reinterpret_cast<uintptr_t>(hnd);
+    if (h == 0 || h > high_water_.load(std::memory_order_acquire)) return nullptr;
+    return &at(static_cast<uint32_t>(h - 1));
+  }
+
+  size_t live_count() {
+    std::lock_guard<std::mutex> g(mu_);
+    return high_water_.load() - free_.size();
+  }
+
+ private:
+  Arena() {
+    for (auto &c : chunks_) c.store(nullptr);
+  }
+  Tensor &at(uint32_t slot) {
+    return chunks_[slot / kChunk].load(std::memory_order_acquire)[slot % kChunk];
+  }
+  std::mutex mu_;
+  std::atomic<size_t> high_water_{0};
+  std::vector<uint32_t> free_;
+  std::atomic<Tensor *> chunks_[kMaxChunks];
+};
+
+}  // namespace
+
+Tensor *lookup(NVTETensor h) { return Arena::get().find(h); }
+
+Tensor *lookup_checked(NVTETensor h) {
+  Tensor *t = Arena::get().find(h);
+  NVTE_CHECK(t != nullptr && t->live, "Invalid tensor.");
+  return t;
+}
+
+NVTEShape Tensor::shape() const {
+  switch (scaling_mode) {
+    case NVTE_DELAYED_TENSOR_SCALING:
+    case NVTE_BLOCK_SCALING_1D:
+    case NVTE_BLOCK_SCALING_2D:
+    case NVTE_NVFP4_1D_SCALING: {
+      if (!has_data() && has_columnwise_data()) {
+        // stored [last, d0, d1, ...]  ->  logical [d0, d1, ..., last]
+        NVTEShape out{{0}, 0};
+        const NVTEShape &c = columnwise_data.shape;
+        if (c.ndim > 0) {
+          for (size_t i = 1; i < c.ndim; ++i) out.data[out.ndim++] = c.data[i];
+          out.data[out.ndim++] = c.data[0];
+        }
+        return out;
+      }
+      return data.shape;
+    }
+    case NVTE_MXFP8_1D_SCALING:
+      return (!has_data() && has_columnwise_data()) ? columnwise_data.shape : data.shape;
+    default:
+      NVTE_ERROR("Cannot parse tensor shape with scaling mode \"", scaling_mode_name(scaling_mode),
+                 "\"");
+  }
+}
+
+std::array<size_t, 2> Tensor::flat2d() const {
+  const NVTEShape s = shape();
+  if (s.ndim == 0) return {1, 1};
+  size_t lead = 1;
+  for (size_t i = 0; i + 1 < s.ndim; ++i) lead *= s.data[i];
+  return {lead, s.data[s.ndim - 1]};
+}
+
+// ------------------------------------------------------------------ validators
+void check_noop(const Tensor &t, const char *name) {
+  if (t.data.ptr != nullptr) {
+    NVTE_CHECK(t.numel() == 1, "Expected 1 element for ", name, " noop, but found ", t.numel(), ".");
+    NVTE_CHECK(t.data.dtype == kNVTEFloat32, "Found wrong dtype for ", name,
+               " noop. Expected kFloat32.");
+  }
+}
+
+static bool shape_is(const NVTEShape &s, size_t a, size_t b) {
+  return s.ndim == 2 && s.data[0] == a && s.data[1] == b;
+}
+
+void check_scale_shapes(const Tensor &t, const char *name) {
+  NVTE_CHECK(t.scaling_mode != NVTE_INVALID_SCALING, "Invalid scaling mode!");
+  if (is_tensor_scaling(t.scaling_mode)) {
+    const size_t want = is_fp8(t.dtype()) ? 1 : 0;
+    if (t.has_data()) {
+      NVTE_CHECK(t.scale_inv.numel() == want, "Tensor \"", name,
+                 "\" has invalid scale_inv shape (expected ", want, " entry, got ", t.scale_inv.shape,
+                 ")");
+    }
+    if (t.has_columnwise_data()) {
+      NVTE_CHECK(t.columnwise_scale_inv.numel() == want, "Tensor \"", name,
+                 "\" has invalid columnwise_scale_inv shape (expected ", want, " entry, got ",
+                 t.columnwise_scale_inv.shape, ")");
+    }
+  } else if (is_mxfp8(t.scaling_mode)) {
+    // Scale matrices are padded to (128, 4) multiples even though each entry is one byte.
+    const auto [r, c] = t.flat2d();
+    if (t.has_data()) {
+      const size_t e0 = round_up(r, 128), e1 = round_up(ceil_div(c, 32), 4);
+      NVTE_CHECK(shape_is(t.scale_inv.shape, e0, e1), "Tensor \"", name,
+                 "\" has invalid scale_inv shape (expected (", e0, ",", e1, "), got ",
+                 t.scale_inv.shape, ")");
+    }
+    if (t.has_columnwise_data()) {
+      const size_t e0 = round_up(ceil_div(r, 32), 4), e1 = round_up(c, 128);
+      NVTE_CHECK(shape_is(t.columnwise_scale_inv.shape, e0, e1), "Tensor \"", name,
+                 "\" has invalid columnwise_scale_inv shape (expected (", e0, ",", e1, "), got ",
+                 t.columnwise_scale_inv.shape, ")");
+    }
+  }
+}
+
+static void check_fp8_scale_inv(const Tensor &t, const char *name, const char *role) {
+  if (t.has_data()) {
+    NVTE_CHECK(t.scale_inv.present(), "FP8 scaling factor ", role, " ", name,
+               "_scale_inverse must be allocated");
+    NVTE_CHECK(t.scale_inv.dtype == kNVTEFloat32 || t.scale_inv.dtype == kNVTEFloat8E8M0,
+               "FP8 scaling factor ", role, " ", name,
+               "_scale_inverse has invalid dtype (expected Float32 or Float8E8M0, got ",
+               dtype_name(t.scale_inv.dtype), ")");
+  }
+  if (t.has_columnwise_data()) {
+    NVTE_CHECK(t.columnwise_scale_inv.present(), "FP8 scaling factor ", role, " ", name,
+               "_columnwise_scale_inverse must be allocated");
+    NVTE_CHECK(t.columnwise_scale_inv.dtype == kNVTEFloat32 ||
+                   t.columnwise_scale_inv.dtype == kNVTEFloat8E8M0,
+               "FP8 scaling factor ", role, " ", name,
+               "_columnwise_scale_inverse has invalid dtype (expected Float32 or Float8E8M0, got ",
+               dtype_name(t.columnwise_scale_inv.dtype), ")");
+  }
+}
+
+void check_input(const Tensor &t, const char *name, bool shapes_too) {
+  if (is_fp8(t.dtype())) {
+    check_fp8_scale_inv(t, name, "input");
+  } else {
+    NVTE_CHECK(!t.scale.present(), "Scale is not supported for non-FP8 input ", name);
+    NVTE_CHECK(!t.scale_inv.present(), "Scale_inv is not supported for non-FP8 input ", name);
+    NVTE_CHECK(!t.columnwise_scale_inv.present(), "Scale_inv is not supported for non-FP8 input ",
+               name);
+  }
+  NVTE_CHECK(t.has_data() || t.has_columnwise_data(), "Input ", name, " is not allocated!");
+  if (shapes_too) check_scale_shapes(t, name);
+}
+
+void check_output(const Tensor &t, const char *name, bool allow_empty) {
+  if (is_fp8(t.dtype())) {
+    if (t.scaling_mode == NVTE_DELAYED_TENSOR_SCALING && t.amax.present()) {
+      NVTE_CHECK(t.amax.dtype == kNVTEFloat32, "Invalid amax dtype (expected Float32, got ",
+                 dtype_name(t.amax.dtype), ")");
+      NVTE_CHECK(t.amax.numel() == 1, "Invalid shape of amax in output ", name,
+                 " (expected 1 entry, got shape=", t.amax.shape, ")");
+    }
+    check_fp8_scale_inv(t, name, "output");
+  } else {
+    NVTE_CHECK(!t.scale.present(), "Scale is not supported for non-FP8 output ", name);
+    NVTE_CHECK(!t.scale_inv.present(), "Scale_inv is not supported for non-FP8 output ", name);
+    NVTE_CHECK(!t.columnwise_scale_inv.present(), "Scale_inv is not supported for non-FP8 output ",
+               name);
+  }
+  if (!allow_empty) {
+    NVTE_CHECK(t.has_data() || t.has_columnwise_data(), "Output ", name, " is not allocated!");
+  }
+  check_scale_shapes(t, name);
+}
+
+const float *noop_ptr_of(const QuantConfig *cfg) {
+  if (cfg == nullptr || cfg->noop_tensor == nullptr) return nullptr;
+  Tensor *n = lookup_checked(cfg->noop_tensor);
+  check_noop(*n, "quantize");
+  return static_cast<const float *>(n->data.ptr);
+}
+
+// ------------------------------------------------------------------ error mode
+namespace {
+std::atomic<int> g_error_mode{0};
+thread_local std::string tl_error;
+thread_local bool tl_has_error = false;
+}  // namespace
+
+int error_mode() { return g_error_mode.load(std::memory_order_relaxed); }
+void record_error(const char *api, const char *what) {
+  tl_error = std::string(api) + ": " + what;
+  tl_has_error = true;
+}
+void api_enter(const char *) { tl_has_error = false; }
+
+// ------------------------------------------------------------------ device info
+const DeviceInfo &device_info() {
+  static std::mutex mu;
+  static DeviceInfo cache[64];
+  static bool have[64] = {false};
+  int dev = 0;
+  NVTE_CHECK_HIP(hipGetDevice(&dev));
+  NVTE_CHECK(dev >= 0 && dev < 64, "device ordinal out of range");
+  std::lock_guard<std::mutex> g(mu);
+  if (!have[dev]) {
+    hipDeviceProp_t p;
+    NVTE_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    cache[dev].num_cus = p.multiProcessorCount;
+    cache[dev].is_gfx950 = std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+    cache[dev].num_xcds = 8;
+    have[dev] = true;
+  }
+  return cache[dev];
+}
+
+}  // namespace te
+
+using namespace te;
+
+// =================================================================== C ABI
+extern "C" {
+
+void nvte_amd_set_error_mode(int mode) { g_error_mode.store(mode ? 1 : 0); }
+int nvte_amd_get_error_mode(void) { return g_error_mode.load(); }
+const char *nvte_amd_last_error(void) { return tl_has_error ? tl_error.c_str() : nullptr; }
+void nvte_amd_clear_error(void) { tl_has_error = false; }
+const char *nvte_amd_version(void) { return "transformerengine_amd 0.1 gfx950"; }
+
+NVTETensor nvte_create_tensor(NVTEScalingMode scaling_mode) {
+  return api_guard("nvte_create_tensor", [&]() -> NVTETensor {
+    NVTETensor h = nullptr;
+    Arena::get().create(scaling_mode, &h, 1);
+    return h;
+  });
+}
+
+void nvte_create_tensors(NVTEScalingMode scaling_mode, NVTETensor *tensors, size_t N) {
+  api_guard("nvte_create_tensors", [&] { Arena::get().create(scaling_mode, tensors, N); });
+}
+
+void nvte_destroy_tensor(NVTETensor tensor) {
+  api_guard("nvte_destroy_tensor", [&] { Arena::get().destroy(&tensor, 1); });
+}
+
+void nvte_destroy_tensors(NVTETensor *tensors, size_t N) {
+  api_guard("nvte_destroy_tensors", [&] {
+    if (tensors != nullptr) Arena::get().destroy(tensors, N);
+  });
+}
+
+NVTEDType nvte_tensor_type(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_type", [&]() -> NVTEDType {
+    Tensor *t = lookup(tensor);
+    return t ? t->dtype() : kNVTEFloat32;
+  });
+}
+
+NVTEShape nvte_make_shape(const size_t *data, size_t ndim) {
+  return api_guard("nvte_make_shape", [&]() -> NVTEShape {
+    NVTEShape s;
+    std::memset(&s, 0, sizeof(s));
+    NVTE_CHECK(ndim <= 15, "Too many dims for NVTEShape (requested: ", ndim, ", max: 15)");
+    if (data != nullptr) std::memcpy(s.data, data, ndim * sizeof(size_t));
+    s.ndim = ndim;
+    return s;
+  });
+}
+
+NVTEShape nvte_tensor_shape(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_shape", [&]() -> NVTEShape {
+    Tensor *t = lookup(tensor);
+    if (t == nullptr) NVTE_ERROR("Invalid tensor: received null pointer in nvte_tensor_shape");
+    return t->shape();
+  });
+}
+
+NVTEShape nvte_tensor_columnwise_shape(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_columnwise_shape", [&]() -> NVTEShape {
+    Tensor *t = lookup(tensor);
+    if (t == nullptr)
+      NVTE_ERROR("Invalid tensor: received null pointer in nvte_tensor_columnwise_shape");
+    return t->columnwise_data.shape;
+  });
+}
+
+size_t nvte_tensor_ndims(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_ndims", [&]() -> size_t { return lookup_checked(tensor)->shape().ndim; });
+}
+
+size_t nvte_tensor_size(const NVTETensor tensor, const size_t dim) {
+  return api_guard("nvte_tensor_size", [&]() -> size_t {
+    const NVTEShape s = lookup_checked(tensor)->shape();
+    NVTE_CHECK(dim < s.ndim, "Attempted to access index ", dim, " in a shape array with ", s.ndim,
+               " entries");
+    return s.data[dim];
+  });
+}
+
+size_t nvte_tensor_numel(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_numel", [&]() -> size_t { return lookup_checked(tensor)->numel(); });
+}
+
+size_t nvte_tensor_element_size_bits(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_element_size_bits", [&]() -> size_t {
+    Tensor *t = lookup(tensor);
+    return t ? dtype_bits(t->dtype()) : 32;
+  });
+}
+
+size_t nvte_tensor_element_size(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_element_size", [&]() -> size_t {
+    Tensor *t = lookup(tensor);
+    if (t == nullptr) return sizeof(float);
+    NVTE_CHECK(t->dtype() != kNVTEFloat4E2M1,
+               "For FP4 type please use the nvte_tensor_element_size_bits.");
+    return dtype_bits(t->dtype()) / 8;
+  });
+}
+
+size_t nvte_tensor_size_bytes(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_size_bytes", [&]() -> size_t {
+    Tensor *t = lookup(tensor);
+    if (t == nullptr) return 0;
+    return t->numel() * dtype_bits(t->dtype()) / 8;
+  });
+}
+
+void *nvte_tensor_data(const NVTETensor tensor) {
+  Tensor *t = lookup(tensor);
+  return t ? t->data.ptr : nullptr;
+}
+
+void *nvte_tensor_columnwise_data(const NVTETensor tensor) {
+  Tensor *t = lookup(tensor);
+  return t ? t->columnwise_data.ptr : nullptr;
+}
+
+float *nvte_tensor_amax(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_amax", [&]() -> float * {
+    Tensor *t = lookup(tensor);
+    if (t == nullptr) return nullptr;
+    NVTE_CHECK(t->amax.dtype == kNVTEFloat32, "Tensor's amax must have Float32 type!");
+    return static_cast<float *>(t->amax.ptr);
+  });
+}
+
+float *nvte_tensor_scale(const NVTETensor tensor) {
+  return api_guard("nvte_tensor_scale", [&]() -> float * {
+    Tensor *t = lookup(tensor);
+    if (t == nullptr) return nullptr;
+    NVTE_CHECK(t->scale.dtype == kNVTEFloat32, "Tensor's scale must have Float32 type!");
+    return static_cast<float *>(t->scale.ptr);
+  });
+}
+
+float *nvte_tensor_scale_inv(const NVTETensor tensor) {
+  Tensor *t = lookup(tensor);
+  return t ? static_cast<float *>(t->scale_inv.ptr) : nullptr;
+}
+
+NVTEShape nvte_tensor_scale_inv_shape(const NVTETensor tensor) {
+  Tensor *t = lookup(tensor);
+  if (t == nullptr) return NVTEShape{{0}, 1};
+  return t->scale_inv.shape;
+}
+
+NVTEScalingMode nvte_tensor_scaling_mode(const NVTETensor tensor) {
+  Tensor *t = lookup(tensor);
+  return t ? t->scaling_mode : NVTE_DELAYED_TENSOR_SCALING;
+}
+
+static Buf *buf_of(Tensor &t, NVTETensorParam p) {
+  switch (p) {
+    case kNVTERowwiseData: return &t.data;
+    case kNVTEColumnwiseData: return &t.columnwise_data;
+    case kNVTEScale: return &t.scale;
+    case kNVTEAmax: return &t.amax;
+    case kNVTERowwiseScaleInv: return &t.scale_inv;
+    case kNVTEColumnwiseScaleInv: return &t.columnwise_scale_inv;
+    case kNVTEColumnwiseAmax: return &t.columnwise_amax;
+    default: return nullptr;
+  }
+}
+
+void nvte_set_tensor_param(NVTETensor *tensor, NVTETensorParam param_name,
+                           const NVTEBasicTensor *param) {
+  api_guard("nvte_set_tensor_param", [&] {
+    NVTE_CHECK(tensor != nullptr, "Tensor pointer can't be NULL.");
+    Tensor *t = lookup(*tensor);
+    NVTE_CHECK(t != nullptr && t->live, "Tensor is not allocated.");
+    NVTE_CHECK(param != nullptr, "Invalid parameter (got NULL)");
+    Buf *b = buf_of(*t, param_name);
+    if (b == nullptr)
+      NVTE_ERROR("Unsupported tensor parameter (", static_cast<int>(param_name),
+                 "). Consider using nvte_set_tensor_param_v2 instead.");
+    *b = Buf(*param);
+  });
+}
+
+NVTEBasicTensor nvte_get_tensor_param(const NVTETensor tensor, NVTETensorParam param_name) {
+  return api_guard("nvte_get_tensor_param", [&]() -> NVTEBasicTensor {
+    if (tensor == nullptr) return Buf().as_basic();
+    Tensor *t = lookup_checked(tensor);
+    Buf *b = buf_of(*t, param_name);
+    if (b == nullptr)
+      NVTE_ERROR("Unsupported tensor parameter (", static_cast<int>(param_name),
+                 "). Consider using nvte_set_tensor_param_v2 instead.");
+    return b->as_basic();
+  });
+}
+
+static size_t tensor_param_size(NVTETensorParam p) {
+  switch (p) {
+    case kNVTEWithGEMMSwizzledScales:
+    case kNVTERowScaledNVFP4: return sizeof(uint8_t);
+    case kNVTENVFP4E4M3Max: return sizeof(int);
+    default: return sizeof(NVTEBasicTensor);
+  }
+}
+
+void nvte_set_tensor_param_v2(NVTETensor tensor, NVTETensorParam param, const void *buf,
+                              size_t size_in_bytes) {
+  api_guard("nvte_set_tensor_param_v2", [&] {
+    NVTE_CHECK(static_cast<int>(param) >= 0 && param < kNVTENumTensorParams,
+               "Invalid NVTETensorParam (got ", static_cast<int>(param), ")");
+    NVTE_CHECK(tensor != nullptr, "Tensor pointer can't be NULL.");
+    Tensor &t = *lookup_checked(tensor);
+    const size_t need = tensor_param_size(param);
+    NVTE_CHECK(size_in_bytes >= need, "Buffer is too small for tensor parameter (parameter ",
+               static_cast<int>(param), " needs ", need, " bytes, but buffer has ", size_in_bytes,
+               " bytes)");
+    NVTE_CHECK(buf != nullptr, "Invalid buffer (got NULL)");
+    if (Buf *b = buf_of(t, param)) {
+      NVTEBasicTensor bt;
+      std::memcpy(&bt, buf, sizeof(bt));
+      *b = Buf(bt);
+    } else if (param == kNVTEWithGEMMSwizzledScales) {
+      t.with_gemm_swizzled_scales = *static_cast<const uint8_t *>(buf) != 0;
+    } else if (param == kNVTERowScaledNVFP4) {
+      t.row_scaled_nvfp4 = *static_cast<const uint8_t *>(buf) != 0;
+    } else {
+      std::memcpy(&t.nvfp4_e4m3_max, buf, sizeof(int));
+    }
+  });
+}
+
+void nvte_get_tensor_param_v2(const NVTETensor tensor, NVTETensorParam param, void *buf,
+                              size_t size_in_bytes, size_t *size_written) {
+  api_guard("nvte_get_tensor_param_v2", [&] {
+    NVTE_CHECK(static_cast<int>(param) >= 0 && param < kNVTENumTensorParams,
+               "Invalid NVTETensorParam (got ", static_cast<int>(param), ")");
+    const size_t need = tensor_param_size(param);
+    if (size_written != nullptr) *size_written = need;
+    if (buf == nullptr) return;
+    NVTE_CHECK(size_in_bytes >= need, "Buffer is too small for tensor parameter (parameter ",
+               static_cast<int>(param), " needs ", need, " bytes, but buffer has ", size_in_bytes,
+               " bytes)");
+    // A null handle reads as a default-constructed descriptor.
+    Tensor dflt;
+    Tensor *t = tensor ? lookup_checked(tensor) : &dflt;
+    if (Buf *b = buf_of(*t, param)) {
+      const NVTEBasicTensor bt = b->as_basic();
+      std::memcpy(buf, &bt, sizeof(bt));
+    } else if (param == kNVTEWithGEMMSwizzledScales) {
+      *static_cast<uint8_t *>(buf) = t->with_gemm_swizzled_scales ? 1 : 0;
+    } else if (param == kNVTERowScaledNVFP4) {
+      *static_cast<uint8_t *>(buf) = t->row_scaled_nvfp4 ? 1 : 0;
+    } else {
+      std::memcpy(buf, &t->nvfp4_e4m3_max, sizeof(int));
+    }
+  });
+}
+
+void nvte_zero_tensor(const NVTETensor tensor, hipStream_t stream) {
+  api_guard("nvte_zero_tensor", [&] {
+    Tensor &t = *lookup_checked(tensor);
+    if (t.data.ptr != nullptr && t.data.bytes() > 0)
+      NVTE_CHECK_HIP(hipMemsetAsync(t.data.ptr, 0, t.data.bytes(), stream));
+    if (t.amax.ptr != nullptr && t.amax.bytes() > 0)
+      NVTE_CHECK_HIP(hipMemsetAsync(t.amax.ptr, 0, t.amax.bytes(), stream));
+  });
+}
+
+void nvte_memset(void *ptr, int value, size_t size_in_bytes, hipStream_t stream) {
+  api_guard("nvte_memset", [&] {
+    if (size_in_bytes == 0) return;
+    NVTE_CHECK(ptr != nullptr, "Pointer for memset must be allocated.");
+    NVTE_CHECK_HIP(hipMemsetAsync(ptr, value, size_in_bytes, stream));
+  });
+}
+
+void nvte_tensor_pack_create(NVTETensorPack *pack) {
+  api_guard("nvte_tensor_pack_create", [&] {
+    NVTE_CHECK(pack != nullptr, "Invalid pack (got NULL)");
+    Arena::get().create(NVTE_DELAYED_TENSOR_SCALING, pack->tensors, NVTE_TENSOR_PACK_MAX_SIZE);
+  });
+}
+
+void nvte_tensor_pack_destroy(NVTETensorPack *pack) {
+  api_guard("nvte_tensor_pack_destroy", [&] {
+    NVTE_CHECK(pack != nullptr, "Invalid pack (got NULL)");
+    Arena::get().destroy(pack->tensors, NVTE_TENSOR_PACK_MAX_SIZE);
+  });
+}
+
+int nvte_is_non_tn_fp8_gemm_supported(void) { return 0; }
+
+// ------------------------------------------------------------------ quantization config
+namespace {
+struct AttrSlot {
+  void *p;
+  size_t n;
+};
+AttrSlot qattr(QuantConfig &c, NVTEQuantizationConfigAttribute a) {
+  switch (a) {
+    case kNVTEQuantizationConfigForcePow2Scales: return {&c.force_pow_2_scales, 1};
+    case kNVTEQuantizationConfigAmaxEpsilon: return {&c.amax_epsilon, sizeof(float)};
+    case kNVTEQuantizationConfigNoopTensor: return {&c.noop_tensor, sizeof(NVTETensor)};
+    case kNVTEQuantizationConfigFloat8BlockScaleTensorFormat:
+      return {&c.float8_block_scale_tensor_format, sizeof(int)};
+    case kNVTEQuantizationConfigRNGState: return {&c.rng_state, sizeof(NVTETensor)};
+    case kNVTEQuantizationConfigNVFP42DQuantization: return {&c.nvfp4_2d_quantization, 1};
+    case kNVTEQuantizationConfigStochasticRounding: return {&c.stochastic_rounding, 1};
+    case kNVTEQuantizationConfigUseFastMath: return {&c.use_fast_math, 1};
+    case kNVTEQuantizationConfigNVFP44Over6Mode: return {&c.nvfp4_4over6_mode, 1};
+    case kNVTEQuantizationConfigNVFP44Over6ErrUseFastMath:
+      return {&c.nvfp4_4over6_err_use_fast_math, 1};
+    default: NVTE_ERROR("Unsupported NVTEQuantizationConfigAttribute (got ", static_cast<int>(a), ")");
+  }
+}
+AttrSlot mattr(MatmulConfig &c, NVTEMatmulConfigAttribute a) {
+  switch (a) {
+    case kNVTEMatmulConfigBiasTensor: return {&c.bias_tensor, sizeof(NVTETensor)};
+    case kNVTEMatmulConfigDBiasTensor: return {&c.dbias_tensor, sizeof(NVTETensor)};
+    case kNVTEMatmulConfigWithGELUEpilogue: return {&c.with_gelu_epilogue, 1};
+    case kNVTEMatmulConfigWithDGELUEpilogue: return {&c.with_dgelu_epilogue, 1};
+    case kNVTEMatmulConfigEpilogueAuxTensor: return {&c.epilogue_aux_tensor, sizeof(NVTETensor)};
+    case kNVTEMatmulConfigUseSplitAccumulator: return {&c.use_split_accumulator, 1};
+    case kNVTEMatmulConfigSMCount: return {&c.sm_count, sizeof(int)};
+    default: NVTE_ERROR("Unsupported NVTEMatmulConfigAttribute (got ", static_cast<int>(a), ")");
+  }
+}
+void attr_get(AttrSlot s, void *buf, size_t size_in_bytes, size_t *size_written) {
+  if (size_written != nullptr) *size_written = s.n;
+  if (buf == nullptr) return;
+  NVTE_CHECK(size_in_bytes >= s.n, "Buffer is too small for config attribute (needs ", s.n,
+             " bytes, but buffer has ", size_in_bytes, " bytes)");
+  std::memcpy(buf, s.p, s.n);
+}
+void attr_set(AttrSlot s, const void *buf, size_t size_in_bytes) {
+  NVTE_CHECK(size_in_bytes >= s.n, "Buffer is too small for config attribute (needs ", s.n,
+             " bytes, but buffer has ", size_in_bytes, " bytes)");
+  NVTE_CHECK(buf != nullptr, "Invalid buffer (got NULL)");
+  std::memcpy(s.p, buf, s.n);
+}
+}  // namespace
+
+NVTEQuantizationConfig nvte_create_quantization_config(void) { return new QuantConfig; }
+
+void nvte_get_quantization_config_attribute(NVTEQuantizationConfig config,
+                                            NVTEQuantizationConfigAttribute attr, void *buf,
+                                            size_t size_in_bytes, size_t *size_written) {
+  api_guard("nvte_get_quantization_config_attribute", [&] {
+    NVTE_CHECK(config != nullptr, "Invalid NVTEQuantizationConfig (got NULL)");
+    attr_get(qattr(*static_cast<QuantConfig *>(config), attr), buf, size_in_bytes, size_written);
+  });
+}
+
+void nvte_set_quantization_config_attribute(NVTEQuantizationConfig config,
+                                            NVTEQuantizationConfigAttribute attr, const void *buf,
+                                            size_t size_in_bytes) {
+  api_guard("nvte_set_quantization_config_attribute", [&] {
+    NVTE_CHECK(config != nullptr, "Invalid NVTEQuantizationConfig (got NULL)");
+    attr_set(qattr(*static_cast<QuantConfig *>(config), attr), buf, size_in_bytes);
+  });
+}
+
+void nvte_destroy_quantization_config(NVTEQuantizationConfig config) {
+  delete static_cast<QuantConfig *>(config);
+}
+
+NVTEMatmulConfig nvte_create_matmul_config(void) { return new MatmulConfig; }
+
+void nvte_get_matmul_config_attribute(NVTEMatmulConfig config, NVTEMatmulConfigAttribute attr,
+                                      void *buf, size_t size_in_bytes, size_t *size_written) {
+  api_guard("nvte_get_matmul_config_attribute", [&] {
+    NVTE_CHECK(config != nullptr, "Invalid NVTEMatmulConfig (got NULL)");
+    attr_get(mattr(*static_cast<MatmulConfig *>(config), attr), buf, size_in_bytes, size_written);
+  });
+}
+
+void nvte_set_matmul_config_attribute(NVTEMatmulConfig config, NVTEMatmulConfigAttribute attr,
+                                      const void *buf, size_t size_in_bytes) {
+  api_guard("nvte_set_matmul_config_attribute", [&] {
+    NVTE_CHECK(config != nullptr, "Invalid NVTEMatmulConfig (got NULL)");
+    attr_set(mattr(*static_cast<MatmulConfig *>(config), attr), buf, size_in_bytes);
+  });
+}
+
+void nvte_destroy_matmul_config(NVTEMatmulConfig config) { delete static_cast<MatmulConfig *>(config); }
+
+}  // extern "C"
