@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Headline benchmark: FP8 Linear fwd+bwd TFLOP/s (+ cast_transpose GB/s) on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--no-graph] [--no-cpu-baseline]
+
+N = 1 : BASELINE.json configs[1] - Llama-3-8B MLP Linear 4096 -> 14336, 8192 tokens, FP8 delayed
+        scaling (HYBRID: E4M3 forward, E5M2 backward), forward + backward.
+        One "step" = quantize X (row+col), GEMM fprop, recipe step (fwd), quantize dY (row+col),
+        GEMM dgrad, GEMM wgrad, recipe step (bwd).  The weight quantize is amortised exactly as
+        te.Linear does with is_first_microbatch=False (cached FP8 weight); its stand-alone cost is
+        reported in "extra".
+N > 1 : the same Linear tensor-parallel + sequence-parallel over N ranks (column-parallel,
+        FP8 all-gather of the input, reduce-scatter of dgrad, amax all-reduce on RCCL), tokens
+        grow with N (8192 per rank) so per-GPU GEMM work is fixed: "scaling": "weak".
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP8_TFLOPS = 5000.0   # dense FP8 MFMA, MI355X_MICROARCH.md "Peak FP8 MFMA ~5 PF dense"
+PEAK_HBM_GBPS = 8000.0     # HBM3E spec, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--tokens", type=int, default=8192)
+    ap.add_argument("--in-features", type=int, default=4096)
+    ap.add_argument("--out-features", type=int, default=14336)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters, warm=3):
+    """Average device time (ms) of fn() measured with events on torch's current stream - the
+    stream every nvte_* call in fn is enqueued on."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def cpu_baseline():
+    """The reference's CPU path (tests/cpp host references, restated in oracle/) on a bounded
+    sample: BASELINE.json configs[0] (Linear 768 -> 3072, 2048 tokens) forward + backward:
+    three cast_transpose+amax (serial loops, as the reference's compute_ref) and three FP32 GEMMs
+    of the dequantized operands (OpenMP over all host cores)."""
+    import numpy as np
+    import oracle
+    M, K, N = 2048, 768, 3072
+    rng = np.random.default_rng(1234)
+    mk = lambda s: oracle.float_to_bf16_bits(rng.standard_normal(s, dtype=np.float32))
+    x, w, dy = mk((M, K)), mk((N, K)), mk((M, N))
+    t0 = time.perf_counter()
+    qx, qxt, ax, sx = oracle.cast_transpose(x, 64.0, oracle.E4M3)
+    qw, qwt, aw, sw = oracle.cast_transpose(w, 64.0, oracle.E4M3)
+    qdy, qdyt, ady, sdy = oracle.cast_transpose(dy, 1024.0, oracle.E5M2)
+    t1 = time.perf_counter()
+    fx, fw, fdy = (oracle.dequant(qx, 0, sx), oracle.dequant(qw, 0, sw), oracle.dequant(qdy, 1, sdy))
+    fwt, fdyt, fxt = (oracle.dequant(qwt, 0, sw), oracle.dequant(qdyt, 1, sdy), oracle.dequant(qxt, 0, sx))
+    t2 = time.perf_counter()
+    oracle.gemm_tn(fx, fw, fast=True)       # fprop  Y  = X W^T
+    oracle.gemm_tn(fdy, fwt, fast=True)     # dgrad  dX = dY W
+    oracle.gemm_tn(fdyt, fxt, fast=True)    # wgrad  dW = dY^T X
+    t3 = time.perf_counter()
+    flops = 6.0 * M * N * K
+    total = (t1 - t0) + (t3 - t2)
+    elems = M * K + N * K + M * N
+    return {
+        "value": flops / total / 1e12, "unit": "TFLOP/s", "cores": oracle.num_threads(), "kind": "port",
+        "sample": "BASELINE configs[0]: Linear 768->3072, 2048 tokens fwd+bwd = 3x cast_transpose+amax "
+                  "(serial reference loops, 1 core) + 3x dequantized-FP32 GEMM (OpenMP, all cores)",
+        "cast_transpose_GBps": elems * 4 / (t1 - t0) / 1e9, "cast_transpose_cores": 1,
+        "gemm_GFLOPs": flops / (t3 - t2) / 1e9, "seconds": total,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import transformer_engine_amd as te
+    from transformer_engine_amd import linear as L
+    from transformer_engine_amd.recipe import DelayedScaling
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    M, K, N = args.tokens, args.in_features, args.out_features
+    torch.manual_seed(1234 + rank)
+    recipe = DelayedScaling()   # HYBRID, history 1024, "max", margin 0 (reference defaults)
+
+    if world == 1:
+        x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+        w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
+        st = L.LinearFP8State(recipe, device=dev)
+
+        def step(first=False):
+            y, saved = L.linear_forward(x, w, None, st, is_first_microbatch=first)
+            st.update_fwd()
+            dx, dw, _ = L.linear_backward(dy, saved, st)
+            st.update_bwd()
+            return y, dx, dw
+
+        flops_per_step = 6.0 * M * N * K
+        parallelism = "single"
+        global_tokens = M
+    else:
+        from transformer_engine_amd import distributed as D
+        mod = D.ColumnParallelLinearSP(K, N, world, rank, recipe, device=dev)
+        x_local = torch.randn(M, K, device=dev, dtype=torch.bfloat16)        # this rank's tokens
+        dy = (torch.randn(M * world, N // world, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
+
+        def step(first=False):
+            return mod.step(x_local, dy, is_first_microbatch=first)
+
+        flops_per_step = 6.0 * (M * world) * N * K      # whole job
+        parallelism = f"tp{world}+sp"
+        global_tokens = M * world
+
+    # warm the scales (>= 2 steps so delayed scaling values are in range), cache the FP8 weight
+    step(first=True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            torch.cuda.synchronize()
+        except Exception as exc:  # capture is an optimisation, not a requirement
+            print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); running eagerly",
+                  file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    run = (lambda: graph.replay()) if graph is not None else (lambda: step())
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    tflops = flops_per_step / (elapsed / args.steps) / 1e12
+
+    result = {
+        "metric": "FP8 Linear fwd+bwd TFLOPS/GPU + cast_transpose GB/s",
+        "value": tflops, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8(e4m3/e5m2)->f32acc", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: Llama-3-8B MLP Linear 4096->14336, FP8 delayed scaling "
+                               "(HYBRID), fwd+bwd, 8192 tokens per GPU",
+                   "tokens": global_tokens, "in_features": K, "out_features": N, "parallelism": parallelism,
+                   "hip_graph": graph is not None, "weight_quantize": "amortised (is_first_microbatch=False)"},
+        "tflops_per_gpu": tflops / world,
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-kernel measurements (HIP events on the launch stream) -------------------------
+        from transformer_engine_amd import general_gemm
+        it = max(10, args.steps // 2)
+        qi, qw, qg = st.fwd_q[L.FWD_INPUT], st.fwd_q[L.FWD_WEIGHT], st.bwd_q[L.BWD_GRAD_OUTPUT]
+        for q in (qi, qw, qg):
+            q.set_usage(rowwise=True, columnwise=True)
+        x8, w8, dy8 = qi(x), qw(w), qg(dy)
+        ox, ow, ody = (q.make_empty(t.shape, dtype=t.dtype, device=dev) for q, t in ((qi, x), (qw, w), (qg, dy)))
+        t_ct_x = time_kernel(lambda: qi.update_quantized(x, ox), it)
+        t_ct_w = time_kernel(lambda: qw.update_quantized(w, ow), it)
+        t_ct_dy = time_kernel(lambda: qg.update_quantized(dy, ody), it)
+        y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+        dw = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
+        t_fprop = time_kernel(lambda: general_gemm(w8, x8, layout="TN", out=y), it)
+        t_dgrad = time_kernel(lambda: general_gemm(w8, dy8, layout="NN", out=dx, grad=True), it)
+        t_wgrad = time_kernel(lambda: general_gemm(x8, dy8, layout="NT", out=dw, grad=True), it)
+        gemm_flops = 2.0 * M * N * K
+        gemm_avg_ms = (t_fprop + t_dgrad + t_wgrad) / 3.0
+        achieved = gemm_flops / (gemm_avg_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
+                              "frac": achieved / PEAK_FP8_TFLOPS, "traffic": None,
+                              "kernel": "gemm_fp8_kernel (fprop/dgrad/wgrad average, 2*M*N*K FLOP per launch)"}
+        ct_bytes = dy.numel() * 4.0      # 2 B read + 1 B rowwise + 1 B transposed per bf16 element
+        ct_gbps = ct_bytes / (t_ct_dy * 1e-3) / 1e9
+        result["roofline_cast_transpose"] = {"bound": "hbm", "achieved": ct_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                             "frac": ct_gbps / PEAK_HBM_GBPS, "traffic": None,
+                                             "kernel": "cast_transpose_tile_kernel on dY [8192,14336] bf16->e5m2, 4 B/element"}
+        result["extra"] = {
+            "gemm_ms": {"fprop": t_fprop, "dgrad": t_dgrad, "wgrad": t_wgrad},
+            "gemm_tflops": {"fprop": gemm_flops / t_fprop / 1e9, "dgrad": gemm_flops / t_dgrad / 1e9,
+                            "wgrad": gemm_flops / t_wgrad / 1e9},
+            "cast_transpose_ms": {"x": t_ct_x, "w": t_ct_w, "dy": t_ct_dy},
+            "cast_transpose_GBps": {"x": x.numel() * 4 / t_ct_x / 1e6, "w": w.numel() * 4 / t_ct_w / 1e6,
+                                    "dy": dy.numel() * 4 / t_ct_dy / 1e6},
+            "gemm_only_tflops": 3 * gemm_flops / ((t_fprop + t_dgrad + t_wgrad) * 1e-3) / 1e12,
+            "weight_quantize_ms_not_in_step": t_ct_w,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,207 @@
+"""FP8 Linear forward + backward: the call sequence of the reference's ``te.Linear``.
+
+Mirrors ``transformer_engine/pytorch/module/linear.py``: ``_linear_forward_impl`` (:262),
+``_linear_backward`` (:760), ``grad_output_preprocess`` (``module/base.py:1622``) and the
+weight-cache rule (``is_first_microbatch``, :450-460):
+
+  forward   X  --quantize(row [+col])--> X8 ;  W --quantize(row+col, cached)--> W8
+            Y  = general_gemm(W8, X8, "TN")            (+bias)
+  backward  dY --quantize(row+col, E5M2 under HYBRID) [+ dbias] --> dY8
+            dX = general_gemm(W8, dY8, "NN", grad=True)
+            dW = general_gemm(X8, dY8, "NT", grad=True, accumulate=fuse_wgrad_accumulation)
+  recipe    delayed scaling: amax history roll + scale update once per fwd and once per bwd
+
+Tensor/sequence parallel variants of the same sequence live in ``distributed.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import torch
+
+from ._lib import api
+from .gemm import general_gemm
+from .recipe import (DelayedScaling, DelayedScalingRecipeState, Float8CurrentScaling,
+                     MXFP8BlockScaling, get_fp8_te_dtype, reduce_and_update_fp8_tensors)
+from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor,
+                     MXFP8Quantizer, MXFP8Tensor, TensorWrapper, current_stream_ptr, wrap_plain)
+
+# quantizer slots, as in the reference (module/base.py:1073: 3 per GEMM fwd, 2 per GEMM bwd)
+FWD_INPUT, FWD_WEIGHT, FWD_OUTPUT = 0, 1, 2
+BWD_GRAD_OUTPUT, BWD_GRAD_INPUT = 0, 1
+
+
+def bgrad_quantize(dy: torch.Tensor, quantizer):
+    """dbias = sum over tokens of dY, fused with the quantize of dY
+    (ref tex.bgrad_quantize, module/base.py:1716 -> nvte_quantize_dbias)."""
+    out = quantizer.make_empty(dy.shape, dtype=dy.dtype, device=dy.device)
+    dbias = torch.empty(dy.shape[-1], dtype=dy.dtype, device=dy.device)
+    stream = current_stream_ptr()
+    wi = wrap_plain(dy)
+    wd = wrap_plain(dbias)
+    ws = TensorWrapper()
+    if isinstance(quantizer, MXFP8Quantizer):
+        wo = out.wrap()
+    else:
+        wo = quantizer._wrap_out(out)
+        if isinstance(quantizer, Float8Quantizer):
+            wo.set_scale(quantizer.scale).set_amax(quantizer.amax)
+        else:
+            raise NotImplementedError("bgrad_quantize with current scaling: quantize then reduce "
+                                      "(the reference also runs these unfused)")
+    api.nvte_quantize_dbias(wi.handle, wo.handle, wd.handle, ws.handle, stream)   # workspace query
+    bt = ws.get_param(0)
+    shape = [bt.shape.data[i] for i in range(bt.shape.ndim)]
+    workspace = torch.empty(shape, dtype=torch.float32, device=dy.device)
+    ws.set_rowwise_data(workspace)
+    api.nvte_quantize_dbias(wi.handle, wo.handle, wd.handle, ws.handle, stream)
+    if isinstance(out, Float8Tensor):
+        out._transpose_invalid = out._transpose is None
+    for w in (wi, wd, ws, wo):
+        w.destroy()
+    return dbias, out
+
+
+class LinearFP8State:
+    """Per-module quantization state: recipe states + quantizers for one Linear."""
+
+    def __init__(self, recipe, device=None):
+        self.recipe = recipe
+        self.device = device or torch.device("cuda")
+        self.fwd_state: Optional[DelayedScalingRecipeState] = None
+        self.bwd_state: Optional[DelayedScalingRecipeState] = None
+        if isinstance(recipe, DelayedScaling):
+            self.fwd_state = DelayedScalingRecipeState(recipe, mode="forward", num_quantizers=3, device=self.device)
+            self.bwd_state = DelayedScalingRecipeState(recipe, mode="backward", num_quantizers=2, device=self.device)
+            self.fwd_q = self.fwd_state.make_quantizers()
+            self.bwd_q = self.bwd_state.make_quantizers()
+        elif isinstance(recipe, Float8CurrentScaling):
+            f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
+            mk = lambda dt: Float8CurrentScalingQuantizer(dt, self.device,
+                                                          force_pow_2_scales=recipe.use_power_2_scales,
+                                                          amax_epsilon=recipe.amax_epsilon)
+            self.fwd_q = [mk(f) for _ in range(3)]
+            self.bwd_q = [mk(b) for _ in range(2)]
+        elif isinstance(recipe, MXFP8BlockScaling):
+            f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
+            self.fwd_q = [MXFP8Quantizer(f) for _ in range(3)]
+            self.bwd_q = [MXFP8Quantizer(b) for _ in range(2)]
+        else:
+            raise TypeError(f"unsupported recipe {type(recipe)}")
+        self.weight_cache = None  # quantized weight kept across microbatches
+
+    # recipe step (delayed scaling only; the other recipes are stateless)
+    def update_fwd(self, group=None):
+        if self.fwd_state is not None:
+            reduce_and_update_fp8_tensors([self.fwd_state], group)
+
+    def update_bwd(self, group=None):
+        if self.bwd_state is not None:
+            reduce_and_update_fp8_tensors([self.bwd_state], group)
+
+
+def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                   st: LinearFP8State, *, is_first_microbatch: Optional[bool] = None,
+                   needs_backward: bool = True, out_dtype: Optional[torch.dtype] = None):
+    """Returns (y, saved) where saved = (x8, w8) for the backward pass."""
+    qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
+    qi.set_usage(rowwise=True, columnwise=needs_backward)          # linear.py:399-406
+    x2d = x.reshape(-1, x.shape[-1])
+    x8 = qi(x2d)                                                   # linear.py:407
+    # weight: quantize on the first microbatch (or always when no caching was requested)
+    if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
+        qw.set_usage(rowwise=True, columnwise=needs_backward)
+        w8 = qw(weight)                                            # linear.py:451-461
+        if is_first_microbatch is not None:
+            st.weight_cache = w8
+    else:
+        w8 = st.weight_cache
+    y, *_ = general_gemm(w8, x8, out_dtype=out_dtype or x.dtype, layout="TN", bias=bias)  # linear.py:507
+    y = y.reshape(*x.shape[:-1], weight.shape[0])
+    return y, (x8, w8)
+
+
+def linear_backward(dy: torch.Tensor, saved, st: LinearFP8State, *, use_bias: bool = False,
+                    wgrad_out: Optional[torch.Tensor] = None, accumulate_wgrad: bool = False,
+                    grad_dtype: Optional[torch.dtype] = None, requires_dgrad: bool = True,
+                    requires_wgrad: bool = True):
+    """Returns (dx, dw, dbias)."""
+    x8, w8 = saved
+    qg = st.bwd_q[BWD_GRAD_OUTPUT]
+    qg.set_usage(rowwise=True, columnwise=True)                    # linear.py:874-876
+    dy2d = dy.reshape(-1, dy.shape[-1])
+    dy2d = dy2d if dy2d.is_contiguous() else dy2d.contiguous()
+    dbias = None
+    if use_bias and not isinstance(qg, Float8CurrentScalingQuantizer):
+        dbias, dy8 = bgrad_quantize(dy2d, qg)                      # base.py:1716
+    else:
+        dy8 = qg(dy2d)                                             # base.py:1718
+        if use_bias:
+            dbias = dy2d.sum(dim=0)
+    gdt = grad_dtype or dy.dtype
+    dx = dw = None
+    if requires_dgrad:
+        dx, *_ = general_gemm(w8, dy8, out_dtype=gdt, layout="NN", grad=True)          # linear.py:1062
+    if requires_wgrad:
+        if wgrad_out is not None:
+            dw, *_ = general_gemm(x8, dy8, layout="NT", grad=True, out=wgrad_out,
+                                  accumulate=accumulate_wgrad)                           # linear.py:1225-1261
+        else:
+            dw, *_ = general_gemm(x8, dy8, out_dtype=gdt, layout="NT", grad=True)
+    return dx, dw, dbias
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, module):
+        st = module.fp8_state
+        y, saved = linear_forward(x, weight, bias, st, is_first_microbatch=module._is_first_microbatch,
+                                  needs_backward=torch.is_grad_enabled())
+        ctx.saved_q = saved
+        ctx.module = module
+        ctx.use_bias = bias is not None
+        ctx.x_shape = x.shape
+        ctx.needs = (x.requires_grad, weight.requires_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m = ctx.module
+        wgrad_out, acc = None, False
+        if m.fuse_wgrad_accumulation and hasattr(m.weight, "main_grad"):
+            wgrad_out, acc = m.weight.main_grad, True
+        dx, dw, dbias = linear_backward(dy, ctx.saved_q, m.fp8_state, use_bias=ctx.use_bias,
+                                        wgrad_out=wgrad_out, accumulate_wgrad=acc,
+                                        requires_dgrad=ctx.needs[0], requires_wgrad=ctx.needs[1])
+        m.fp8_state.update_bwd(m.amax_group)
+        if dx is not None:
+            dx = dx.reshape(ctx.x_shape)
+        if acc:
+            dw = None
+        return dx, dw, dbias, None
+
+
+class Linear(torch.nn.Module):
+    """``te.Linear`` look-alike for one GPU (same constructor names for the arguments it has)."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True,
+                 params_dtype: torch.dtype = torch.bfloat16, device="cuda",
+                 fuse_wgrad_accumulation: bool = False, recipe=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = torch.nn.Parameter(torch.empty(out_features, in_features, dtype=params_dtype, device=device))
+        torch.nn.init.normal_(self.weight, std=0.02)
+        self.bias = torch.nn.Parameter(torch.zeros(out_features, dtype=params_dtype, device=device)) if bias else None
+        self.fuse_wgrad_accumulation = fuse_wgrad_accumulation
+        self.fp8_state = LinearFP8State(recipe or DelayedScaling(), device=torch.device(device))
+        self._is_first_microbatch = None
+        self.amax_group = None
+
+    def forward(self, x: torch.Tensor, is_first_microbatch: Optional[bool] = None) -> torch.Tensor:
+        self._is_first_microbatch = is_first_microbatch
+        y = _LinearFn.apply(x, self.weight, self.bias, self)
+        # the reference runs the forward recipe step when the autocast region exits
+        # (quantization.py:762); one module == one region here
+        self.fp8_state.update_fwd(self.amax_group)
+        return y
