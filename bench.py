@@ -153,7 +153,7 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
+    use_graph = (not args.no_graph) and world == 1   # RCCL collectives are left out of graph capture
     graph = None
     if use_graph:
         try:

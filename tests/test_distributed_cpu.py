@@ -1,0 +1,99 @@
+"""world_size-2 gloo tests (CPU) of the TP/SP chunk bookkeeping in transformer_engine_amd.distributed:
+the collectives move the right rows to the right ranks and the overlap schedules produce the same
+result as gather-then-matmul / matmul-then-reduce-scatter."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn_name, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        globals()[fn_name](rank, world)
+        ret[rank] = "ok"
+    except Exception as e:  # pragma: no cover
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name, world=2):
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, fn_name, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", ret.get(r)
+
+
+def _case_gather_and_gemm(rank, world):
+    from transformer_engine_amd import distributed as D
+    g = torch.Generator().manual_seed(7)
+    full = torch.randint(0, 255, (world * 6, 8), generator=g, dtype=torch.uint8)   # "FP8 bytes"
+    w = torch.randn(5, 8, generator=g)
+    local = full[rank * 6:(rank + 1) * 6].clone()
+    y = torch.zeros(world * 6, 5)
+    order = []
+
+    def gemm(shard, r):
+        order.append(r)
+        y[r * 6:(r + 1) * 6] = shard.float() @ w.t()
+
+    gathered = D.gather_and_gemm_by_shard(local, gemm, None)
+    assert torch.equal(gathered, full)                     # bit-exact all-gather of bytes
+    assert order[0] == rank and sorted(order) == list(range(world))
+    assert torch.equal(y, full.float() @ w.t())
+    # plain all-gather agrees
+    out, _ = D.all_gather_rows(local, None)
+    assert torch.equal(out, full)
+
+
+def _case_gemm_and_reduce_scatter(rank, world):
+    from transformer_engine_amd import distributed as D
+    g = torch.Generator().manual_seed(9)
+    dy_all = [torch.randn(world * 4, 3, generator=g) for _ in range(world)]   # per-rank partial operands
+    w_all = [torch.randn(3, 6, generator=g) for _ in range(world)]
+    expect = sum(dy_all[r] @ w_all[r] for r in range(world))
+
+    def gemm(row0, rows):
+        return dy_all[rank][row0:row0 + rows] @ w_all[rank]
+
+    mine = D.gemm_and_reduce_scatter_by_block(world * 4, gemm, None)
+    assert torch.allclose(mine, expect[rank * 4:(rank + 1) * 4], atol=1e-5)
+
+
+def _case_amax_reduction(rank, world):
+    """delayed-scaling amax buffer: ONE MAX all-reduce of the packed buffer (ref quantization.py:666-674)."""
+    buf = torch.tensor([1.0 + rank, 5.0 - rank, 0.0])
+    dist.all_reduce(buf, op=dist.ReduceOp.MAX)
+    assert torch.equal(buf, torch.tensor([float(world), 5.0, 0.0]))
+
+
+def test_gather_and_gemm_overlap_schedule():
+    _run("_case_gather_and_gemm")
+
+
+def test_gemm_and_reduce_scatter_overlap_schedule():
+    _run("_case_gemm_and_reduce_scatter")
+
+
+def test_amax_max_reduction():
+    _run("_case_amax_reduction")

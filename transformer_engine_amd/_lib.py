@@ -171,6 +171,7 @@ class _Api:
             fn.argtypes = args
         lib.nvte_amd_set_error_mode(1)
         self._last_error = lib.nvte_amd_last_error
+        self._clear_error = lib.nvte_amd_clear_error
         self._cache = {}
 
     def __getattr__(self, name):
@@ -179,12 +180,13 @@ class _Api:
         fn = self._cache.get(name)
         if fn is None:
             raw = getattr(self._lib, name)
-            last_error = self._last_error
+            last_error, clear_error = self._last_error, self._clear_error
 
             def fn(*a, _raw=raw):
                 r = _raw(*a)
                 e = last_error()
                 if e is not None:
+                    clear_error()
                     raise NVTEError(e.decode("utf-8", "replace"))
                 return r
 

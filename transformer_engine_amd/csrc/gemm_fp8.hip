@@ -506,7 +506,7 @@ using namespace te;
 
 extern "C" {
 
-void nvte_cublas_handle_init(void) {}
+void nvte_cublas_handle_init(void) { api_enter("nvte_cublas_handle_init"); }
 
 void nvte_cublas_gemm(const NVTETensor A, const NVTETensor B, NVTETensor D, const NVTETensor bias,
                       NVTETensor pre_gelu_out, bool transa, bool transb, bool grad,

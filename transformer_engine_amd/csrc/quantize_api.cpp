@@ -183,7 +183,10 @@ void nvte_multi_cast_transpose(size_t num_tensors, const NVTETensor *input_list,
   });
 }
 
-int nvte_get_num_compute_streams(void) { return kNumStreams; }
+int nvte_get_num_compute_streams(void) {
+  api_enter("nvte_get_num_compute_streams");
+  return kNumStreams;
+}
 
 hipStream_t nvte_get_compute_stream(const int idx) {
   return api_guard("nvte_get_compute_stream", [&]() -> hipStream_t {

@@ -421,11 +421,13 @@ size_t nvte_tensor_size_bytes(const NVTETensor tensor) {
 }
 
 void *nvte_tensor_data(const NVTETensor tensor) {
+  api_enter("nvte_tensor_data");
   Tensor *t = lookup(tensor);
   return t ? t->data.ptr : nullptr;
 }
 
 void *nvte_tensor_columnwise_data(const NVTETensor tensor) {
+  api_enter("nvte_tensor_columnwise_data");
   Tensor *t = lookup(tensor);
   return t ? t->columnwise_data.ptr : nullptr;
 }
@@ -449,17 +451,20 @@ float *nvte_tensor_scale(const NVTETensor tensor) {
 }
 
 float *nvte_tensor_scale_inv(const NVTETensor tensor) {
+  api_enter("nvte_tensor_scale_inv");
   Tensor *t = lookup(tensor);
   return t ? static_cast<float *>(t->scale_inv.ptr) : nullptr;
 }
 
 NVTEShape nvte_tensor_scale_inv_shape(const NVTETensor tensor) {
+  api_enter("nvte_tensor_scale_inv_shape");
   Tensor *t = lookup(tensor);
   if (t == nullptr) return NVTEShape{{0}, 1};
   return t->scale_inv.shape;
 }
 
 NVTEScalingMode nvte_tensor_scaling_mode(const NVTETensor tensor) {
+  api_enter("nvte_tensor_scaling_mode");
   Tensor *t = lookup(tensor);
   return t ? t->scaling_mode : NVTE_DELAYED_TENSOR_SCALING;
 }
@@ -598,7 +603,10 @@ void nvte_tensor_pack_destroy(NVTETensorPack *pack) {
   });
 }
 
-int nvte_is_non_tn_fp8_gemm_supported(void) { return 0; }
+int nvte_is_non_tn_fp8_gemm_supported(void) {
+  api_enter("nvte_is_non_tn_fp8_gemm_supported");
+  return 0;
+}
 
 // ------------------------------------------------------------------ quantization config
 namespace {
@@ -650,7 +658,10 @@ void attr_set(AttrSlot s, const void *buf, size_t size_in_bytes) {
 }
 }  // namespace
 
-NVTEQuantizationConfig nvte_create_quantization_config(void) { return new QuantConfig; }
+NVTEQuantizationConfig nvte_create_quantization_config(void) {
+  api_enter("nvte_create_quantization_config");
+  return new QuantConfig;
+}
 
 void nvte_get_quantization_config_attribute(NVTEQuantizationConfig config,
                                             NVTEQuantizationConfigAttribute attr, void *buf,
@@ -671,10 +682,14 @@ void nvte_set_quantization_config_attribute(NVTEQuantizationConfig config,
 }
 
 void nvte_destroy_quantization_config(NVTEQuantizationConfig config) {
+  api_enter("nvte_destroy_quantization_config");
   delete static_cast<QuantConfig *>(config);
 }
 
-NVTEMatmulConfig nvte_create_matmul_config(void) { return new MatmulConfig; }
+NVTEMatmulConfig nvte_create_matmul_config(void) {
+  api_enter("nvte_create_matmul_config");
+  return new MatmulConfig;
+}
 
 void nvte_get_matmul_config_attribute(NVTEMatmulConfig config, NVTEMatmulConfigAttribute attr,
                                       void *buf, size_t size_in_bytes, size_t *size_written) {
@@ -692,6 +707,9 @@ void nvte_set_matmul_config_attribute(NVTEMatmulConfig config, NVTEMatmulConfigA
   });
 }
 
-void nvte_destroy_matmul_config(NVTEMatmulConfig config) { delete static_cast<MatmulConfig *>(config); }
+void nvte_destroy_matmul_config(NVTEMatmulConfig config) {
+  api_enter("nvte_destroy_matmul_config");
+  delete static_cast<MatmulConfig *>(config);
+}
 
 }  // extern "C"
