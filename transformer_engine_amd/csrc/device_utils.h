@@ -168,9 +168,15 @@ __device__ __forceinline__ float block_max(float v, float *scratch) {
 }
 
 // amax values are >= 0, so their fp32 bit patterns order like unsigned ints
-// (ref common/utils.cuh:935: int-punned atomicMax).
+// (ref common/utils.cuh:935: int-punned atomicMax).  The target only ever grows during a
+// launch, so a relaxed device-scope read that already shows a value >= v makes the atomic
+// redundant even if the read is stale; thousands of same-address atomics per launch
+// otherwise serialise at the memory side (measured: 7168 of them cost ~13 us).
 __device__ __forceinline__ void atomic_max_nonneg(float *addr, float v) {
-  atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+  unsigned int *p = reinterpret_cast<unsigned int *>(addr);
+  const unsigned int bits = __float_as_uint(v);
+  const unsigned int seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bits > seen) atomicMax(p, bits);
 }
 
 // ------------------------------------------------------------------ byte shuffles

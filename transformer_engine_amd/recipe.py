@@ -121,9 +121,10 @@ def reduce_and_update_fp8_tensors(states: List[DelayedScalingRecipeState], group
         return
     recipe = states[0].recipe
     contiguous_amax = torch.cat([s.amax_history[0] for s in states])
-    if recipe.reduce_amax and group is not None:
+    if recipe.reduce_amax:
         import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        # group=None means the default (world) group, as in torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(contiguous_amax, op=dist.ReduceOp.MAX, group=group)
     fused_amax_and_scale_update_after_reduction(
         contiguous_amax, [s.amax_history for s in states], [s.scale for s in states],
