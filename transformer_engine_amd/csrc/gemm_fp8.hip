@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -58,6 +59,7 @@ struct GemmArgs {
   unsigned ldd;
   unsigned eP_stride, eQ_stride;  // compact layout row stride (bytes)
   unsigned eP_swz, eQ_swz;        // 1 = GEMM-swizzled 128x4 tiles
+  unsigned eP_bytes, eQ_bytes;    // size of the scale buffers
   float alpha, beta;
   int d_dtype;     // NVTEDType of D
   int bias_dtype;  // NVTEDType of bias
@@ -118,7 +120,7 @@ __device__ __forceinline__ unsigned scale_row_offset(unsigned row, unsigned nrow
 }
 
 template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX>
-__global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(kThreads) void gemm_fp8_kernel_v1(const GemmArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes];
 
   const unsigned tid = threadIdx.x;
@@ -337,12 +339,387 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// v2: same tile / LDS image as v1, but
+//  * MFMA fragments are pulled out of LDS one quarter-step (4 MFMAs) ahead of their use into
+//    alternating register sets, so the matrix pipe never waits on LDS;
+//  * ONE barrier per 128-byte K tile, placed before the last quarter-step: by then every wave
+//    has pulled all of tile t out of LDS slot t&1, so the slot is refilled with
+//    tile t+2 immediately, a full tile before it is needed (the loads of tile t+1, issued one
+//    tile ago, are what the barrier's vmcnt(0) waits for);
+//  * the accumulators leave through a wave-private LDS transpose so that global stores are
+//    full 128/256-byte row segments (8 or 16 bytes per lane) instead of 2-byte scatters.
+template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, int ABL = 0>
+__global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes];
+  typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wi = wave >> 2, wj = wave & 3u;
+
+  const unsigned tiles_i = (a.n + BM - 1) / BM;
+  unsigned ti, tj;
+  tile_of(blockIdx.x, a.ntiles, tiles_i, a.tiles_j, ti, tj);
+  const unsigned i0 = ti * BM, j0 = tj * BN;
+
+  const unsigned rows_p = min(a.n - i0, static_cast<unsigned>(BM));
+  const unsigned rows_q = min(a.m - j0, static_cast<unsigned>(BN));
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(a.P) + static_cast<size_t>(i0) * a.k, 0, rows_p * a.k, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(a.Q) + static_cast<size_t>(j0) * a.k, 0, rows_q * a.k, 0x00020000);
+
+  // Staging geometry: wave-instruction q of this wave fills tile rows (wave*4+q)*8 .. +7, lane ->
+  // (row = lane >> 3, LDS chunk slot = lane & 7).  The swizzle of a row only depends on
+  // (q & 1, lane), so two lane offsets serve the four instructions; the row block and the K
+  // position travel in the scalar offset.
+  unsigned st_voff[2], st_chunk_k[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const unsigned r = static_cast<unsigned>(q) * 8 + (lane >> 3);
+    const unsigned c = (lane & 7u) ^ ((r >> 1) & 7u);
+    st_voff[q] = (lane >> 3) * a.k + c * 16;
+    st_chunk_k[q] = c * 16;
+  }
+  // two glds instructions (rows q*8.. of this wave's 32-row share of P and of Q)
+  auto stage_rows = [&](unsigned slot, unsigned k0, int q, const unsigned (&voff)[2]) {
+    uint8_t *base = lds + slot * kStageBytes;
+    const unsigned soff = (wave * 4 + q) * 8 * a.k + k0;
+    lds_u8 *dst_p = (lds_u8 *)(base + (wave * 4 + q) * 1024);
+    lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, 0);
+  };
+  auto stage_voff = [&](unsigned k0, unsigned (&voff)[2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) voff[q] = (k0 + st_chunk_k[q] < a.k) ? st_voff[q] : kOOB;
+  };
+  auto stage = [&](unsigned slot, unsigned k0) {
+    unsigned voff[2];
+    stage_voff(k0, voff);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stage_rows(slot, k0, q, voff);
+  };
+
+  // Fragment read geometry.  A lane needs chunks c = half + 2q (q = 0..3) of its row; with the
+  // swizzle s = (row >> 1) & 7 the chunk sits at c ^ s = (half ^ (s & 1)) + 2 (q ^ (s >> 1)), and
+  // both s & 1 and s >> 1 only depend on lane & 31 (rows of different MFMA tiles differ by
+  // multiples of 32).  So 4 lane-constant offsets serve every tile; the tile's row block is an
+  // immediate.
+  const unsigned fr_row = lane & 31u;
+  const unsigned fr_half = lane >> 5;
+  const unsigned sw = (fr_row >> 1) & 7u;
+  unsigned offP[4], offQ[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned chunk = (fr_half ^ (sw & 1u)) + 2u * (static_cast<unsigned>(q) ^ (sw >> 1));
+    offP[q] = (wi * 128 + fr_row) * BK + chunk * 16;
+    offQ[q] = BM * BK + (wj * 64 + fr_row) * BK + chunk * 16;
+  }
+  // one MFMA operand fragment: P row block mi / Q column block nj, K step ks of the tile in `slot`
+  auto rdP = [&](unsigned slot, int ks, int mi, v8i &f) {
+    if constexpr (ABL & 4) return;
+    const uint8_t *img = lds + slot * kStageBytes;
+    const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offP[2 * ks] + mi * 32 * BK);
+    const u32x4 hi = *reinterpret_cast<const u32x4 *>(img + offP[2 * ks + 1] + mi * 32 * BK);
+    f = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  auto rdQ = [&](unsigned slot, int ks, int nj, v8i &f) {
+    if constexpr (ABL & 4) return;
+    const uint8_t *img = lds + slot * kStageBytes;
+    const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offQ[2 * ks] + nj * 32 * BK);
+    const u32x4 hi = *reinterpret_cast<const u32x4 *>(img + offQ[2 * ks + 1] + nj * 32 * BK);
+    f = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+
+  v16f acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+  const unsigned nk = (a.k + BK - 1) / BK;
+
+  // MX scales: one dword = the 4 K blocks of a tile for one row (scX current, nxX in flight).
+  // The descriptors cover exactly the scale buffers, so rows of a partial tile that lie past
+  // the (padded) buffer read 0; rows past n / m inside the padding only feed outputs that are
+  // never stored.  Lane part of the address in one VGPR, row block + K tile in the scalar offset.
+  uint32_t scP[4] = {0, 0, 0, 0}, scQ[2] = {0, 0};
+  uint32_t nxP[4] = {0, 0, 0, 0}, nxQ[2] = {0, 0};
+  __amdgpu_buffer_rsrc_t re_p, re_q;
+  unsigned svP = 0, svQ = 0, sbP[4] = {0, 0, 0, 0}, sbQ[2] = {0, 0}, sstepP = 0, sstepQ = 0;
+  if constexpr (MX) {
+    re_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eP), 0, a.eP_bytes, 0x00020000);
+    re_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eQ), 0, a.eQ_bytes, 0x00020000);
+    sstepP = a.eP_swz ? 512u : 4u;
+    sstepQ = a.eQ_swz ? 512u : 4u;
+    svP = a.eP_swz ? fr_row * 16 : fr_row * a.eP_stride;
+    svQ = a.eQ_swz ? fr_row * 16 : fr_row * a.eQ_stride;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const unsigned row0 = i0 + wi * 128 + mi * 32;  // multiple of 32
+      sbP[mi] = a.eP_swz ? (row0 / 128) * (a.eP_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eP_stride;
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const unsigned row0 = j0 + wj * 64 + nj * 32;
+      sbQ[nj] = a.eQ_swz ? (row0 / 128) * (a.eQ_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eQ_stride;
+    }
+  }
+  auto load_scales = [&](unsigned kt) {
+    if constexpr (MX) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        nxP[mi] = __builtin_amdgcn_raw_buffer_load_b32(re_p, svP, sbP[mi] + kt * sstepP, 0);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+        nxQ[nj] = __builtin_amdgcn_raw_buffer_load_b32(re_q, svQ, sbQ[nj] + kt * sstepQ, 0);
+    }
+  };
+  // Pre-shift so that opsel 0 / 2 pick this lane's K block.  K blocks past the end of K carry
+  // whatever the padded scale buffer holds: force 2^0 there (their payload bytes are
+  // zero-filled).  Branch-free on purpose: a branch in the main loop lets the optimiser sink
+  // the MFMAs out of their place in the pipeline.
+  auto commit_scales = [&](unsigned kt) {
+    if constexpr (MX) {
+      const unsigned kbase = min(kt * BK, a.k);
+      const unsigned valid = min(4u, (a.k - kbase + 31) / 32);
+      const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * valid)) - 1u);
+      const uint32_t fill = 0x7F7F7F7Fu & ~keep;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) scP[mi] = ((nxP[mi] & keep) | fill) >> (8 * fr_half);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) scQ[nj] = ((nxQ[nj] & keep) | fill) >> (8 * fr_half);
+    }
+  };
+  // one MFMA: acc[mi][nj] += P fragment x Q fragment (K step KS selects the scale bytes)
+  auto mm = [&](auto ks_tag, auto mi_tag, auto nj_tag, const v8i &fp, const v8i &fq) {
+    constexpr int KS = decltype(ks_tag)::value;
+    constexpr int MI = decltype(mi_tag)::value;
+    constexpr int NJ = decltype(nj_tag)::value;
+    if constexpr (ABL & 2) {
+      asm volatile("" ::"v"(fp), "v"(fq));
+    } else if constexpr (MX) {
+      acc[MI][NJ] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+          fp, fq, acc[MI][NJ], FA, FB, 2 * KS, (int)scP[MI], 2 * KS, (int)scQ[NJ]);
+    } else {
+      acc[MI][NJ] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fp, fq, acc[MI][NJ], FA, FB, 0, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // pin the hand-made interleave of MFMA / LDS / global->LDS
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  // Two register sets for the P fragments (row blocks 0-1 / 2-3) and two for the Q fragments
+  // (K step 0 / 1); every fragment is re-read from LDS 3..6 MFMAs before its next use, and the
+  // LDS / global->LDS instructions are issued in the shadow of the MFMAs (one MFMA occupies the
+  // matrix pipe for 64 cycles).
+  v8i pa[2], pb[2], q0[2], q1[2];
+  if constexpr (ABL & 4) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const v8i seed = {(int)lane, 1, 2, 3, 4, 5, 6, (int)wave + x};
+      pa[x] = pb[x] = q0[x] = q1[x] = seed;
+    }
+  }
+
+  // prologue: tiles 0 and 1 in flight (tile 1 is an all-zero fill when nk == 1)
+  stage(0, 0);
+  load_scales(0);
+  stage(1, BK);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  commit_scales(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  rdP(0, 0, 0, pa[0]);
+  rdQ(0, 0, 0, q0[0]);
+  rdQ(0, 0, 1, q0[1]);
+  rdP(0, 0, 1, pa[1]);
+  load_scales(1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (unsigned kt = 0; kt < nk; ++kt) {
+    const unsigned cur = kt & 1u, nxt = cur ^ 1u;
+    // quarter 1: K [0,64) x row blocks 0-1
+    mm(I0{}, I0{}, I0{}, pa[0], q0[0]);
+    rdP(cur, 0, 2, pb[0]);
+    mm(I0{}, I0{}, I1{}, pa[0], q0[1]);
+    rdP(cur, 0, 3, pb[1]);
+    mm(I0{}, I1{}, I0{}, pa[1], q0[0]);
+    rdQ(cur, 1, 0, q1[0]);
+    mm(I0{}, I1{}, I1{}, pa[1], q0[1]);
+    // quarter 2: K [0,64) x row blocks 2-3
+    rdP(cur, 1, 0, pa[0]);
+    mm(I0{}, I2{}, I0{}, pb[0], q0[0]);
+    rdQ(cur, 1, 1, q1[1]);
+    mm(I0{}, I2{}, I1{}, pb[0], q0[1]);
+    rdP(cur, 1, 1, pa[1]);
+    mm(I0{}, I3{}, I0{}, pb[1], q0[0]);
+    mm(I0{}, I3{}, I1{}, pb[1], q0[1]);
+    // quarter 3: K [64,128) x row blocks 0-1
+    rdP(cur, 1, 2, pb[0]);
+    mm(I1{}, I0{}, I0{}, pa[0], q1[0]);
+    rdP(cur, 1, 3, pb[1]);
+    mm(I1{}, I0{}, I1{}, pa[0], q1[1]);
+    unsigned voff[2];
+    stage_voff((kt + 2) * BK, voff);
+    mm(I1{}, I1{}, I0{}, pa[1], q1[0]);
+    mm(I1{}, I1{}, I1{}, pa[1], q1[1]);
+    // Every wave has now pulled all of tile kt out of slot `cur`; tile kt+1 (issued one tile
+    // ago) has landed.  Refill the slot with tile kt+2 (past the end of K: zero fill, never read).
+    if constexpr (ABL & 8)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // timing experiment only (racy)
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // quarter 4: K [64,128) x row blocks 2-3; in its shadow the 8 global->LDS loads of tile
+    // kt+2 and the first fragments of tile kt+1
+    mm(I1{}, I2{}, I0{}, pb[0], q1[0]);
+    if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 0, voff);
+    rdP(nxt, 0, 0, pa[0]);
+    if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 1, voff);
+    mm(I1{}, I2{}, I1{}, pb[0], q1[1]);
+    rdQ(nxt, 0, 0, q0[0]);
+    if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 2, voff);
+    mm(I1{}, I3{}, I0{}, pb[1], q1[0]);
+    rdQ(nxt, 0, 1, q0[1]);
+    if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 3, voff);
+    mm(I1{}, I3{}, I1{}, pb[1], q1[1]);
+    rdP(nxt, 0, 1, pa[1]);
+    commit_scales(kt + 1);  // past the last tile: reads of the scale buffer are range-checked
+    load_scales(kt + 2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the trailing zero-fill stages must be out of LDS before the epilogue reuses it
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ------------------------------------------------------------ epilogue
+  float mult = a.alpha;
+  if constexpr (!MX) {
+    if (a.sP) mult *= *a.sP;
+    if (a.sQ) mult *= *a.sQ;
+  }
+  // Wave-private LDS transpose, one 32 x 64 MFMA row block at a time.  Row stride 72 dwords:
+  // the two lane halves (rows +4) land 32 banks apart, so the b32 writes are conflict-free and
+  // each b128 read instruction covers 4 rows x 256 contiguous bytes.
+  constexpr unsigned kStgStride = 72;
+  float *stg = reinterpret_cast<float *>(lds) + wave * (32 * kStgStride);
+  const unsigned e_row = lane >> 4;          // 0..3
+  const unsigned e_col = (lane & 15u) * 4u;  // 0..60
+  const unsigned jbase = j0 + wj * 64 + e_col;
+  auto epilogue = [&](auto *dptr, auto with_c) {
+    using OT = std::remove_pointer_t<decltype(dptr)>;
+    constexpr bool WITH_C = decltype(with_c)::value;
+    using VecT = std::conditional_t<sizeof(OT) == 4, u32x4, u32x2>;
+    const bool vec_ok = (a.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(dptr) % sizeof(VecT)) == 0) &&
+                        (jbase + 3 < a.m);
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (jbase + q < a.m) bias[q] = load_any(a.bias, jbase + q, a.bias_dtype);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stg[((r & 3) + 8 * (r >> 2) + 4 * fr_half) * kStgStride + nj * 32 + fr_row] = acc[mi][nj][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const unsigned lr = p * 4 + e_row;
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + lr * kStgStride + e_col);
+        const unsigned i = i0 + wi * 128 + mi * 32 + lr;
+        if (i >= a.n) continue;
+        OT *dst = dptr + static_cast<size_t>(i) * a.ldd + jbase;
+        float v[4] = {t[0] * mult, t[1] * mult, t[2] * mult, t[3] * mult};
+        if (vec_ok) {
+          if constexpr (WITH_C) {
+            OT old[4];
+            *reinterpret_cast<VecT *>(old) = *reinterpret_cast<const VecT *>(dst);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += a.beta * widen(old[q]);
+          }
+          OT o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) narrow(v[q] + bias[q], o[q]);
+          *reinterpret_cast<VecT *>(dst) = *reinterpret_cast<const VecT *>(o);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (jbase + q >= a.m) continue;
+            float x = v[q];
+            if constexpr (WITH_C) x += a.beta * widen(dst[q]);
+            narrow(x + bias[q], dst[q]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  };
+  const bool with_c = a.beta != 0.f;
+  switch (a.d_dtype) {
+    case kNVTEFloat32:
+      with_c ? epilogue(static_cast<float *>(a.D), std::true_type{}) : epilogue(static_cast<float *>(a.D), std::false_type{});
+      break;
+    case kNVTEBFloat16:
+      with_c ? epilogue(static_cast<bf16_t *>(a.D), std::true_type{}) : epilogue(static_cast<bf16_t *>(a.D), std::false_type{});
+      break;
+    default:
+      with_c ? epilogue(static_cast<f16_t *>(a.D), std::true_type{}) : epilogue(static_cast<f16_t *>(a.D), std::false_type{});
+      break;
+  }
+}
+
+inline bool use_v1() {
+  static const bool v = [] { const char *e = std::getenv("NVTE_AMD_GEMM_V1"); return e && e[0] == '1'; }();
+  return v;
+}
+
+// Experiment switch (perf work only; not part of the API): drop parts of the main loop of
+// the e4m3 x e4m3 kernel to see what bounds it.  bit0 = no global->LDS loads, bit1 = no MFMAs,
+// bit2 = no LDS fragment reads.
+inline int ablate() {
+  static const int v = [] { const char *e = std::getenv("NVTE_AMD_GEMM_ABLATE"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+inline void launch_ablated(int abl, dim3 grid, dim3 block, hipStream_t stream, const GemmArgs &args) {
+  switch (abl) {
+    case 1: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 1>), grid, block, 0, stream, args); break;
+    case 2: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 2>), grid, block, 0, stream, args); break;
+    case 3: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 3>), grid, block, 0, stream, args); break;
+    case 4: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 4>), grid, block, 0, stream, args); break;
+    case 5: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 5>), grid, block, 0, stream, args); break;
+    case 6: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 6>), grid, block, 0, stream, args); break;
+    case 8: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 8>), grid, block, 0, stream, args); break;
+    case 14: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 14>), grid, block, 0, stream, args); break;
+    default: hipLaunchKernelGGL((gemm_fp8_kernel<0, 0, false, 0>), grid, block, 0, stream, args); break;
+  }
+}
+
 template <bool MX>
 void launch_by_format(int fa, int fb, const GemmArgs &args, hipStream_t stream) {
   const dim3 grid(args.ntiles), block(kThreads);
 #define TE_GEMM_CASE(A_, B_)                                                                       \
   if (fa == A_ && fb == B_) {                                                                      \
-    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX>), grid, block, 0, stream, args);              \
+    if (use_v1())                                                                                  \
+      hipLaunchKernelGGL((gemm_fp8_kernel_v1<A_, B_, MX>), grid, block, 0, stream, args);         \
+    else if (A_ == 0 && B_ == 0 && !MX && ablate() != 0)                                          \
+      launch_ablated(ablate(), grid, block, stream, args);                                        \
+    else                                                                                           \
+      hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX>), grid, block, 0, stream, args);            \
     NVTE_CHECK_HIP(hipGetLastError());                                                             \
     return;                                                                                        \
   }
@@ -362,6 +739,7 @@ struct Operand {
   DType dtype = kNVTEByte;
   const void *scale_inv = nullptr;
   unsigned scale_stride = 0;
+  size_t scale_bytes = 0;
   bool swizzled = false;
 };
 
@@ -446,11 +824,13 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     opA.scale_inv = A.scale_inv.ptr;
     opA.scale_stride = static_cast<unsigned>(A.scale_inv.shape.data[A.scale_inv.shape.ndim - 1]);
     opA.swizzled = A.with_gemm_swizzled_scales;
+    opA.scale_bytes = A.scale_inv.numel();
     opB.data = static_cast<const uint8_t *>(B.data.ptr);
     opB.dtype = B.data.dtype;
     opB.scale_inv = B.scale_inv.ptr;
     opB.scale_stride = static_cast<unsigned>(B.scale_inv.shape.data[B.scale_inv.shape.ndim - 1]);
     opB.swizzled = B.with_gemm_swizzled_scales;
+    opB.scale_bytes = B.scale_inv.numel();
     NVTE_CHECK(is_fp8(opA.dtype) && is_fp8(opB.dtype), "MXFP8 GEMM needs FP8 payloads");
     NVTE_CHECK(opA.scale_inv != nullptr && opB.scale_inv != nullptr,
                "FP8 input to GEMM requires inverse of scale!");
@@ -480,6 +860,8 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     g.eP_stride = opB.scale_stride;
     g.eQ_stride = opA.scale_stride;
     g.eP_swz = opB.swizzled;
+    g.eP_bytes = static_cast<unsigned>(std::min<size_t>(opB.scale_bytes, 0xFFFFFFFFu));
+    g.eQ_bytes = static_cast<unsigned>(std::min<size_t>(opA.scale_bytes, 0xFFFFFFFFu));
     g.eQ_swz = opA.swizzled;
   } else {
     g.sP = static_cast<const float *>(opB.scale_inv);
