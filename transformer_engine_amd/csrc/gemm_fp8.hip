@@ -341,9 +341,9 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel_v1(const GemmArgs a)
 
 // ---------------------------------------------------------------------------------------
 // v2: same tile / LDS image as v1, but
-//  * MFMA fragments are pulled out of LDS one quarter-step (4 MFMAs) ahead of their use into
-//    alternating register sets, so the matrix pipe never waits on LDS;
-//  * ONE barrier per 128-byte K tile, placed before the last quarter-step: by then every wave
+//  * every MFMA fragment register is refilled from LDS right after its last use, 5..7 MFMAs
+//    before its next one, so the matrix pipe never waits on LDS;
+//  * ONE barrier per 128-byte K tile, placed after MFMA 10 of 16: by then every wave
 //    has pulled all of tile t out of LDS slot t&1, so the slot is refilled with
 //    tile t+2 immediately, a full tile before it is needed (the loads of tile t+1, issued one
 //    tile ago, are what the barrier's vmcnt(0) waits for);
@@ -516,16 +516,17 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
 
-  // Two register sets for the P fragments (row blocks 0-1 / 2-3) and two for the Q fragments
-  // (K step 0 / 1); every fragment is re-read from LDS 3..6 MFMAs before its next use, and the
-  // LDS / global->LDS instructions are issued in the shadow of the MFMAs (one MFMA occupies the
-  // matrix pipe for 64 cycles).
-  v8i pa[2], pb[2], q0[2], q1[2];
+  // Fragment registers: p[mi] holds row block mi, q[ks][nj] column block nj of K step ks.  Each
+  // register is refilled from LDS right after the last MFMA that reads it, 5..7 MFMAs before its
+  // next use, and the LDS / global->LDS instructions are issued in the shadow of the MFMAs (one
+  // MFMA occupies the matrix pipe for 64 cycles).  MFMA order inside a tile: K step 0 over the
+  // 4 x 2 blocks, then K step 1.
+  v8i p[4], q[2][2];
   if constexpr (ABL & 4) {
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+    for (int x = 0; x < 4; ++x) {
       const v8i seed = {(int)lane, 1, 2, 3, 4, 5, 6, (int)wave + x};
-      pa[x] = pb[x] = q0[x] = q1[x] = seed;
+      p[x] = q[x >> 1][x & 1] = seed;
     }
   }
 
@@ -537,42 +538,39 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   commit_scales(0);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  rdP(0, 0, 0, pa[0]);
-  rdQ(0, 0, 0, q0[0]);
-  rdQ(0, 0, 1, q0[1]);
-  rdP(0, 0, 1, pa[1]);
+  rdP(0, 0, 0, p[0]);
+  rdQ(0, 0, 0, q[0][0]);
+  rdQ(0, 0, 1, q[0][1]);
+  rdP(0, 0, 1, p[1]);
+  rdP(0, 0, 2, p[2]);
+  rdP(0, 0, 3, p[3]);
   load_scales(1);
   __builtin_amdgcn_sched_barrier(0);
 
   for (unsigned kt = 0; kt < nk; ++kt) {
     const unsigned cur = kt & 1u, nxt = cur ^ 1u;
-    // quarter 1: K [0,64) x row blocks 0-1
-    mm(I0{}, I0{}, I0{}, pa[0], q0[0]);
-    rdP(cur, 0, 2, pb[0]);
-    mm(I0{}, I0{}, I1{}, pa[0], q0[1]);
-    rdP(cur, 0, 3, pb[1]);
-    mm(I0{}, I1{}, I0{}, pa[1], q0[0]);
-    rdQ(cur, 1, 0, q1[0]);
-    mm(I0{}, I1{}, I1{}, pa[1], q0[1]);
-    // quarter 2: K [0,64) x row blocks 2-3
-    rdP(cur, 1, 0, pa[0]);
-    mm(I0{}, I2{}, I0{}, pb[0], q0[0]);
-    rdQ(cur, 1, 1, q1[1]);
-    mm(I0{}, I2{}, I1{}, pb[0], q0[1]);
-    rdP(cur, 1, 1, pa[1]);
-    mm(I0{}, I3{}, I0{}, pb[1], q0[0]);
-    mm(I0{}, I3{}, I1{}, pb[1], q0[1]);
-    // quarter 3: K [64,128) x row blocks 0-1
-    rdP(cur, 1, 2, pb[0]);
-    mm(I1{}, I0{}, I0{}, pa[0], q1[0]);
-    rdP(cur, 1, 3, pb[1]);
-    mm(I1{}, I0{}, I1{}, pa[0], q1[1]);
+    mm(I0{}, I0{}, I0{}, p[0], q[0][0]);
+    rdQ(cur, 1, 0, q[1][0]);
+    mm(I0{}, I0{}, I1{}, p[0], q[0][1]);
+    rdP(cur, 1, 0, p[0]);
+    mm(I0{}, I1{}, I0{}, p[1], q[0][0]);
+    rdQ(cur, 1, 1, q[1][1]);
+    mm(I0{}, I1{}, I1{}, p[1], q[0][1]);
+    rdP(cur, 1, 1, p[1]);
+    mm(I0{}, I2{}, I0{}, p[2], q[0][0]);
+    mm(I0{}, I2{}, I1{}, p[2], q[0][1]);
+    rdP(cur, 1, 2, p[2]);
+    mm(I0{}, I3{}, I0{}, p[3], q[0][0]);
+    mm(I0{}, I3{}, I1{}, p[3], q[0][1]);
+    rdP(cur, 1, 3, p[3]);
+    mm(I1{}, I0{}, I0{}, p[0], q[1][0]);
     unsigned voff[2];
     stage_voff((kt + 2) * BK, voff);
-    mm(I1{}, I1{}, I0{}, pa[1], q1[0]);
-    mm(I1{}, I1{}, I1{}, pa[1], q1[1]);
-    // Every wave has now pulled all of tile kt out of slot `cur`; tile kt+1 (issued one tile
-    // ago) has landed.  Refill the slot with tile kt+2 (past the end of K: zero fill, never read).
+    mm(I1{}, I0{}, I1{}, p[0], q[1][1]);
+    // Every wave has now pulled all of tile kt out of slot `cur` (last read: two MFMAs ago);
+    // tile kt+1 (issued most of a tile ago) has landed.  After the barrier the slot is refilled
+    // with tile kt+2 (past the end of K: zero fill, never read) and the first fragments of tile
+    // kt+1 are fetched.
     if constexpr (ABL & 8)
       asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // timing experiment only (racy)
     else
@@ -580,20 +578,22 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // quarter 4: K [64,128) x row blocks 2-3; in its shadow the 8 global->LDS loads of tile
-    // kt+2 and the first fragments of tile kt+1
-    mm(I1{}, I2{}, I0{}, pb[0], q1[0]);
+    rdP(nxt, 0, 0, p[0]);
+    rdQ(nxt, 0, 0, q[0][0]);
+    mm(I1{}, I1{}, I0{}, p[1], q[1][0]);
+    rdQ(nxt, 0, 1, q[0][1]);
     if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 0, voff);
-    rdP(nxt, 0, 0, pa[0]);
+    mm(I1{}, I1{}, I1{}, p[1], q[1][1]);
+    rdP(nxt, 0, 1, p[1]);
     if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 1, voff);
-    mm(I1{}, I2{}, I1{}, pb[0], q1[1]);
-    rdQ(nxt, 0, 0, q0[0]);
+    mm(I1{}, I2{}, I0{}, p[2], q[1][0]);
     if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 2, voff);
-    mm(I1{}, I3{}, I0{}, pb[1], q1[0]);
-    rdQ(nxt, 0, 1, q0[1]);
+    mm(I1{}, I2{}, I1{}, p[2], q[1][1]);
+    rdP(nxt, 0, 2, p[2]);
     if constexpr (!(ABL & 1)) stage_rows(cur, (kt + 2) * BK, 3, voff);
-    mm(I1{}, I3{}, I1{}, pb[1], q1[1]);
-    rdP(nxt, 0, 1, pa[1]);
+    mm(I1{}, I3{}, I0{}, p[3], q[1][0]);
+    mm(I1{}, I3{}, I1{}, p[3], q[1][1]);
+    rdP(nxt, 0, 3, p[3]);
     commit_scales(kt + 1);  // past the last tile: reads of the scale buffer are range-checked
     load_scales(kt + 2);
     __builtin_amdgcn_sched_barrier(0);
