@@ -44,6 +44,24 @@ def parse():
     return ap.parse_args()
 
 
+def load_traffic():
+    """Fabric-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
+    gfx950 + WRITE_SIZE, see profiles/README.md).  Counters cannot be read from inside this
+    process, so the figures come from the separate profiled run of the same kernels and shapes."""
+    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        return json.load(fh)
+
+
+def traffic_of(table, kernel, grid):
+    for key, rec in table.items():
+        if key.startswith(kernel) and key.endswith(f"grid={grid}"):
+            return rec.get("traffic_bytes_per_launch")
+    return None
+
+
 def time_kernel(fn, iters, warm=3):
     """Average device time (ms) of fn() measured with events on torch's current stream - the
     stream every nvte_* call in fn is enqueued on."""
@@ -59,21 +77,22 @@ def time_kernel(fn, iters, warm=3):
     return s.elapsed_time(e) / iters
 
 
-def cpu_baseline():
+def cpu_baseline(tokens=4096, K=4096, N=14336):
     """The reference's CPU path (tests/cpp host references, restated in oracle/) on a bounded
-    sample: BASELINE.json configs[0] (Linear 768 -> 3072, 2048 tokens) forward + backward:
-    three cast_transpose+amax (serial loops, as the reference's compute_ref) and three FP32 GEMMs
-    of the dequantized operands (OpenMP over all host cores)."""
+    sample of the SAME workload: the configs[1] Linear (4096 -> 14336, full-size weight) forward +
+    backward on `tokens` of its 8192 tokens: three cast_transpose+amax (serial loops, as the
+    reference's compute_ref) and three FP32 GEMMs of the dequantized operands (OpenMP over the
+    host cores the process may use)."""
     import numpy as np
     import oracle
-    M, K, N = 2048, 768, 3072
+    M = tokens
     rng = np.random.default_rng(1234)
-    mk = lambda s: oracle.float_to_bf16_bits(rng.standard_normal(s, dtype=np.float32))
-    x, w, dy = mk((M, K)), mk((N, K)), mk((M, N))
+    mk = lambda s, sc: oracle.float_to_bf16_bits(rng.standard_normal(s, dtype=np.float32) * np.float32(sc))
+    x, w, dy = mk((M, K), 1.0), mk((N, K), 0.02), mk((M, N), 0.01)
     t0 = time.perf_counter()
     qx, qxt, ax, sx = oracle.cast_transpose(x, 64.0, oracle.E4M3)
-    qw, qwt, aw, sw = oracle.cast_transpose(w, 64.0, oracle.E4M3)
-    qdy, qdyt, ady, sdy = oracle.cast_transpose(dy, 1024.0, oracle.E5M2)
+    qw, qwt, aw, sw = oracle.cast_transpose(w, 2048.0, oracle.E4M3)
+    qdy, qdyt, ady, sdy = oracle.cast_transpose(dy, 65536.0, oracle.E5M2)
     t1 = time.perf_counter()
     fx, fw, fdy = (oracle.dequant(qx, 0, sx), oracle.dequant(qw, 0, sw), oracle.dequant(qdy, 1, sdy))
     fwt, fdyt, fxt = (oracle.dequant(qwt, 0, sw), oracle.dequant(qdyt, 1, sdy), oracle.dequant(qxt, 0, sx))
@@ -87,8 +106,9 @@ def cpu_baseline():
     elems = M * K + N * K + M * N
     return {
         "value": flops / total / 1e12, "unit": "TFLOP/s", "cores": oracle.num_threads(), "kind": "port",
-        "sample": "BASELINE configs[0]: Linear 768->3072, 2048 tokens fwd+bwd = 3x cast_transpose+amax "
-                  "(serial reference loops, 1 core) + 3x dequantized-FP32 GEMM (OpenMP, all cores)",
+        "sample": f"configs[1] Linear {K}->{N} fwd+bwd on {M} of its 8192 tokens (full-size weight): "
+                  "3x cast_transpose+amax (serial reference loops, 1 core) + 3x dequantized-FP32 GEMM "
+                  "(OpenMP, `cores` threads); dequantize-to-FP32 staging excluded",
         "cast_transpose_GBps": elems * 4 / (t1 - t0) / 1e9, "cast_transpose_cores": 1,
         "gemm_GFLOPs": flops / (t3 - t2) / 1e9, "seconds": total,
     }
@@ -229,13 +249,20 @@ def main():
         gemm_flops = 2.0 * M * N * K
         gemm_avg_ms = (t_fprop + t_dgrad + t_wgrad) / 3.0
         achieved = gemm_flops / (gemm_avg_ms * 1e-3) / 1e12
+        traffic = load_traffic()
+        tiles = lambda r, c: ((r + 255) // 256) * ((c + 255) // 256) * 512
+        g_traffic = [traffic_of(traffic, "gemm_fp8_kernel", g) for g in (tiles(M, N), tiles(M, K), tiles(N, K))]
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
-                              "frac": achieved / PEAK_FP8_TFLOPS, "traffic": None,
+                              "frac": achieved / PEAK_FP8_TFLOPS,
+                              "traffic": (sum(g_traffic) / 3.0) if all(t is not None for t in g_traffic) else None,
+                              "traffic_unit": "bytes/launch (fabric side: HBM + Infinity Cache; fprop/dgrad/wgrad mean)",
                               "kernel": "gemm_fp8_kernel (fprop/dgrad/wgrad average, 2*M*N*K FLOP per launch)"}
         ct_bytes = dy.numel() * 4.0      # 2 B read + 1 B rowwise + 1 B transposed per bf16 element
         ct_gbps = ct_bytes / (t_ct_dy * 1e-3) / 1e9
         result["roofline_cast_transpose"] = {"bound": "hbm", "achieved": ct_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                             "frac": ct_gbps / PEAK_HBM_GBPS, "traffic": None,
+                                             "frac": ct_gbps / PEAK_HBM_GBPS,
+                                             "traffic": traffic_of(traffic, "cast_transpose_tile_kernel", (M // 128) * (N // 128) * 256),
+                                             "algorithmic_bytes": ct_bytes,
                                              "kernel": "cast_transpose_tile_kernel on dY [8192,14336] bf16->e5m2, 4 B/element"}
         result["extra"] = {
             "gemm_ms": {"fprop": t_fprop, "dgrad": t_dgrad, "wgrad": t_wgrad},
