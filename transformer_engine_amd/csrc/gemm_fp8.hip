@@ -48,6 +48,7 @@ constexpr int BN = 256;   // tile cols   (index j, rows of Q)
 constexpr int BK = 128;   // bytes of K per stage
 constexpr int kThreads = 512;
 constexpr int kStageBytes = (BM + BN) * BK;  // 64 KiB
+constexpr int kEpilogueBytes = 32 * 1024;    // 8 waves x 4 KiB transpose staging
 constexpr unsigned kOOB = 0x80000000u;
 
 struct GemmArgs {
@@ -69,6 +70,7 @@ struct GemmArgs {
   int bias_dtype;  // NVTEDType of bias
   unsigned tiles_j;  // number of tile columns
   unsigned ntiles;
+  unsigned grid;     // persistent workgroups (<= ntiles)
 };
 
 // XCD-aware, bijective remap of the flat workgroup id: workgroups that share an XCD
@@ -111,50 +113,69 @@ __device__ __forceinline__ float load_any(const void *p, size_t idx, int dtype) 
   }
 }
 
-// Byte offset of the MX scale dword (4 consecutive K blocks) of `row` for K-stage 0; the
-// per-stage increment is 4 (compact layout) or 512 (swizzled 128x4 tiles).
-__device__ __forceinline__ unsigned scale_row_offset(unsigned row, unsigned nrows, unsigned stride,
-                                                     unsigned swz) {
-  row = min(row, nrows - 1);
-  if (swz) {
-    const unsigned tiles_x = stride / 4;
-    return (row / 128) * tiles_x * 512 + (row % 32) * 16 + ((row % 128) / 32) * 4;
-  }
-  return row * stride;
-}
-
 // Main-loop pipeline:
 //  * every MFMA fragment register is refilled from LDS right after its last use, 5..7 MFMAs
 //    before its next one, so the matrix pipe never waits on LDS; LDS and global->LDS
 //    instructions are issued in the shadow of the MFMAs (hand-made order, pinned with
 //    sched_barrier);
 //  * ONE barrier per 128-byte K tile, placed after MFMA 10 of 16: by then every wave has pulled
-//    all of tile t out of LDS slot t&1, so the slot is refilled with tile t+2 immediately, a
-//    full tile before it is needed (the loads of tile t+1, issued one tile ago, are what the
+//    all of K tile t out of LDS slot t&1, so the slot is refilled with K tile t+2 immediately, a
+//    full tile before it is needed (the loads of K tile t+1, issued one tile ago, are what the
 //    barrier's vmcnt(0) waits for);
-//  * the accumulators leave through a wave-private LDS transpose so that global stores are
-//    full 128/256-byte row segments (8 or 16 bytes per lane) instead of 2-byte scatters.
+//  * PERSISTENT workgroups: workgroup w walks output tiles w, w + grid, w + 2 grid, ... and the
+//    K-tile pipeline runs straight across output-tile boundaries: the last two K tiles of an
+//    output tile already stage the first two K tiles of the next one, so neither the load
+//    latency of a fresh tile nor the drain of the previous tile's stores is exposed;
+//  * the accumulators leave through a wave-private LDS transpose (its own 32 KiB of LDS, the
+//    two pipeline slots stay live) so that global stores are full 128/256-byte row segments.
 template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes + kEpilogueBytes];
   typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned wi = wave >> 2, wj = wave & 3u;
-
   const unsigned tiles_i = (a.n + BM - 1) / BM;
-  unsigned ti, tj;
-  tile_of(blockIdx.x, a.ntiles, tiles_i, a.tiles_j, ti, tj);
-  const unsigned i0 = ti * BM, j0 = tj * BN;
+  const unsigned nk = (a.k + BK - 1) / BK;
 
-  const unsigned rows_p = min(a.n - i0, static_cast<unsigned>(BM));
-  const unsigned rows_q = min(a.m - j0, static_cast<unsigned>(BN));
-  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t *>(a.P) + static_cast<size_t>(i0) * a.k, 0, rows_p * a.k, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t *>(a.Q) + static_cast<size_t>(j0) * a.k, 0, rows_q * a.k, 0x00020000);
+  // Everything that changes from one output tile to the next (all wave-uniform).  The buffer
+  // descriptors cover exactly the tile's rows: rows past the matrix end and explicit kOOB
+  // offsets read as zero; an invalid tile (past the end of this workgroup's list) gets empty
+  // descriptors, so the loads staged "for the next tile" become harmless zero fills.
+  struct TileCtx {
+    uint8_t *pbase, *qbase;      // first row of the tile in P / Q
+    unsigned pbytes, qbytes;     // bytes the tile's descriptors may touch (0 = everything reads 0)
+    unsigned i0, j0;
+    unsigned sbP[4], sbQ[2];  // MX: scalar part of the scale addresses
+  };
+  auto make_tile = [&](unsigned tile, bool valid) {
+    TileCtx t;
+    unsigned ti, tj;
+    tile_of(valid ? tile : 0u, a.ntiles, tiles_i, a.tiles_j, ti, tj);
+    t.i0 = ti * BM;
+    t.j0 = tj * BN;
+    const unsigned rows_p = valid ? min(a.n - t.i0, static_cast<unsigned>(BM)) : 0u;
+    const unsigned rows_q = valid ? min(a.m - t.j0, static_cast<unsigned>(BN)) : 0u;
+    t.pbase = const_cast<uint8_t *>(a.P) + static_cast<size_t>(t.i0) * a.k;
+    t.qbase = const_cast<uint8_t *>(a.Q) + static_cast<size_t>(t.j0) * a.k;
+    t.pbytes = rows_p * a.k;
+    t.qbytes = rows_q * a.k;
+    if constexpr (MX) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const unsigned row0 = t.i0 + wi * 128 + mi * 32;  // multiple of 32
+        t.sbP[mi] = a.eP_swz ? (row0 / 128) * (a.eP_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eP_stride;
+      }
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const unsigned row0 = t.j0 + wj * 64 + nj * 32;
+        t.sbQ[nj] = a.eQ_swz ? (row0 / 128) * (a.eQ_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eQ_stride;
+      }
+    }
+    return t;
+  };
 
   // Staging geometry: wave-instruction q of this wave fills tile rows (wave*4+q)*8 .. +7, lane ->
   // (row = lane >> 3, LDS chunk slot = lane & 7).  The swizzle of a row only depends on
@@ -169,23 +190,25 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     st_chunk_k[q] = c * 16;
   }
   // two glds instructions (rows q*8.. of this wave's 32-row share of P and of Q)
-  auto stage_rows = [&](unsigned slot, unsigned k0, int q, const unsigned (&voff)[2]) {
+  auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
     uint8_t *base = lds + slot * kStageBytes;
     const unsigned soff = (wave * 4 + q) * 8 * a.k + k0;
     lds_u8 *dst_p = (lds_u8 *)(base + (wave * 4 + q) * 1024);
     lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(t.qbase, 0, t.qbytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, 0);
   };
-  auto stage_voff = [&](unsigned k0, unsigned (&voff)[2]) {
+  auto stage_voff = [&](unsigned k0, unsigned(&voff)[2]) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) voff[q] = (k0 + st_chunk_k[q] < a.k) ? st_voff[q] : kOOB;
   };
-  auto stage = [&](unsigned slot, unsigned k0) {
+  auto stage = [&](const TileCtx &t, unsigned slot, unsigned k0) {
     unsigned voff[2];
     stage_voff(k0, voff);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stage_rows(slot, k0, q, voff);
+    for (int q = 0; q < 4; ++q) stage_rows(t, slot, k0, q, voff);
   };
 
   // Fragment read geometry.  A lane needs chunks c = half + 2q (q = 0..3) of its row; with the
@@ -204,6 +227,9 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     offQ[q] = BM * BK + (wj * 64 + fr_row) * BK + chunk * 16;
   }
   // one MFMA operand fragment: P row block mi / Q column block nj, K step ks of the tile in `slot`
+  // (operand register map of v_mfma_*_32x32x64_f8f6f4, measured on gfx950: a lane's first 16
+  // bytes are K = 16*half + [0,16), its last 16 bytes K = 32 + 16*half + [0,16); the 32-element
+  // block b takes its e8m0 scale from lane half b)
   auto rdP = [&](unsigned slot, int ks, int mi, v8i &f) {
     const uint8_t *img = lds + slot * kStageBytes;
     const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offP[2 * ks] + mi * 32 * BK);
@@ -218,23 +244,24 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   };
 
   v16f acc[4][2];
+  auto zero_acc = [&] {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+      for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+  };
+  zero_acc();
 
-  const unsigned nk = (a.k + BK - 1) / BK;
-
-  // MX scales: one dword = the 4 K blocks of a tile for one row (scX current, nxX in flight).
+  // MX scales: one dword = the 4 K blocks of a K tile for one row (scX current, nxX in flight).
   // The descriptors cover exactly the scale buffers, so rows of a partial tile that lie past
   // the (padded) buffer read 0; rows past n / m inside the padding only feed outputs that are
   // never stored.  Lane part of the address in one VGPR, row block + K tile in the scalar offset.
   uint32_t scP[4] = {0, 0, 0, 0}, scQ[2] = {0, 0};
   uint32_t nxP[4] = {0, 0, 0, 0}, nxQ[2] = {0, 0};
   __amdgpu_buffer_rsrc_t re_p, re_q;
-  unsigned svP = 0, svQ = 0, sbP[4] = {0, 0, 0, 0}, sbQ[2] = {0, 0}, sstepP = 0, sstepQ = 0;
+  unsigned svP = 0, svQ = 0, sstepP = 0, sstepQ = 0;
   if constexpr (MX) {
     re_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eP), 0, a.eP_bytes, 0x00020000);
     re_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eQ), 0, a.eQ_bytes, 0x00020000);
@@ -242,25 +269,15 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     sstepQ = a.eQ_swz ? 512u : 4u;
     svP = a.eP_swz ? fr_row * 16 : fr_row * a.eP_stride;
     svQ = a.eQ_swz ? fr_row * 16 : fr_row * a.eQ_stride;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const unsigned row0 = i0 + wi * 128 + mi * 32;  // multiple of 32
-      sbP[mi] = a.eP_swz ? (row0 / 128) * (a.eP_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eP_stride;
-    }
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-      const unsigned row0 = j0 + wj * 64 + nj * 32;
-      sbQ[nj] = a.eQ_swz ? (row0 / 128) * (a.eQ_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eQ_stride;
-    }
   }
-  auto load_scales = [&](unsigned kt) {
+  auto load_scales = [&](const TileCtx &t, unsigned kt) {
     if constexpr (MX) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
-        nxP[mi] = __builtin_amdgcn_raw_buffer_load_b32(re_p, svP, sbP[mi] + kt * sstepP, 0);
+        nxP[mi] = __builtin_amdgcn_raw_buffer_load_b32(re_p, svP, t.sbP[mi] + kt * sstepP, 0);
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj)
-        nxQ[nj] = __builtin_amdgcn_raw_buffer_load_b32(re_q, svQ, sbQ[nj] + kt * sstepQ, 0);
+        nxQ[nj] = __builtin_amdgcn_raw_buffer_load_b32(re_q, svQ, t.sbQ[nj] + kt * sstepQ, 0);
     }
   };
   // Pre-shift so that opsel 0 / 2 pick this lane's K block.  K blocks past the end of K carry
@@ -299,30 +316,16 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
 
   // Fragment registers: p[mi] holds row block mi, q[ks][nj] column block nj of K step ks.  Each
   // register is refilled from LDS right after the last MFMA that reads it, 5..7 MFMAs before its
-  // next use, and the LDS / global->LDS instructions are issued in the shadow of the MFMAs (one
-  // MFMA occupies the matrix pipe for 64 cycles).  MFMA order inside a tile: K step 0 over the
-  // 4 x 2 blocks, then K step 1.
+  // next use.  MFMA order inside a K tile: K step 0 over the 4 x 2 blocks, then K step 1.
   v8i p[4], q[2][2];
 
-  // prologue: tiles 0 and 1 in flight (tile 1 is an all-zero fill when nk == 1)
-  stage(0, 0);
-  load_scales(0);
-  stage(1, BK);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  commit_scales(0);
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  rdP(0, 0, 0, p[0]);
-  rdQ(0, 0, 0, q[0][0]);
-  rdQ(0, 0, 1, q[0][1]);
-  rdP(0, 0, 1, p[1]);
-  rdP(0, 0, 2, p[2]);
-  rdP(0, 0, 3, p[3]);
-  load_scales(1);
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (unsigned kt = 0; kt < nk; ++kt) {
-    const unsigned cur = kt & 1u, nxt = cur ^ 1u;
+  // One K tile: 16 MFMAs + the reads of the next K tile's first fragments + the staging of the
+  // K tile two ahead (`st` / `st_k0`: which output tile and which K offset that is) + the MX
+  // scale hand-over.  `g` counts K tiles across output tiles and picks the LDS slot.
+  auto k_tile = [&](unsigned g, const TileCtx &st, unsigned st_k0, unsigned st_kt, unsigned commit_kt,
+                    auto prefetch_tag) {
+    constexpr bool PREFETCH = decltype(prefetch_tag)::value;  // fetch the next K tile's first fragments
+    const unsigned cur = g & 1u, nxt = cur ^ 1u;
     mm(I0{}, I0{}, I0{}, p[0], q[0][0]);
     rdQ(cur, 1, 0, q[1][0]);
     mm(I0{}, I0{}, I1{}, p[0], q[0][1]);
@@ -339,124 +342,185 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     rdP(cur, 1, 3, p[3]);
     mm(I1{}, I0{}, I0{}, p[0], q[1][0]);
     unsigned voff[2];
-    stage_voff((kt + 2) * BK, voff);
+    stage_voff(st_k0, voff);
     mm(I1{}, I0{}, I1{}, p[0], q[1][1]);
-    // Every wave has now pulled all of tile kt out of slot `cur` (last read: two MFMAs ago);
-    // tile kt+1 (issued most of a tile ago) has landed.  After the barrier the slot is refilled
-    // with tile kt+2 (past the end of K: zero fill, never read) and the first fragments of tile
-    // kt+1 are fetched.
+    // Every wave has now pulled all of this K tile out of slot `cur` (last read: two MFMAs ago);
+    // the next K tile (issued most of a tile ago) has landed.  After the barrier the slot is
+    // refilled with the K tile two ahead and the first fragments of the next one are fetched.
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    rdP(nxt, 0, 0, p[0]);
-    rdQ(nxt, 0, 0, q[0][0]);
+    if constexpr (PREFETCH) rdP(nxt, 0, 0, p[0]);
+    if constexpr (PREFETCH) rdQ(nxt, 0, 0, q[0][0]);
     mm(I1{}, I1{}, I0{}, p[1], q[1][0]);
-    rdQ(nxt, 0, 1, q[0][1]);
-    stage_rows(cur, (kt + 2) * BK, 0, voff);
+    if constexpr (PREFETCH) rdQ(nxt, 0, 1, q[0][1]);
+    stage_rows(st, cur, st_k0, 0, voff);
     mm(I1{}, I1{}, I1{}, p[1], q[1][1]);
-    rdP(nxt, 0, 1, p[1]);
-    stage_rows(cur, (kt + 2) * BK, 1, voff);
+    if constexpr (PREFETCH) rdP(nxt, 0, 1, p[1]);
+    stage_rows(st, cur, st_k0, 1, voff);
     mm(I1{}, I2{}, I0{}, p[2], q[1][0]);
-    stage_rows(cur, (kt + 2) * BK, 2, voff);
+    stage_rows(st, cur, st_k0, 2, voff);
     mm(I1{}, I2{}, I1{}, p[2], q[1][1]);
-    rdP(nxt, 0, 2, p[2]);
-    stage_rows(cur, (kt + 2) * BK, 3, voff);
+    if constexpr (PREFETCH) rdP(nxt, 0, 2, p[2]);
+    stage_rows(st, cur, st_k0, 3, voff);
     mm(I1{}, I3{}, I0{}, p[3], q[1][0]);
     mm(I1{}, I3{}, I1{}, p[3], q[1][1]);
-    rdP(nxt, 0, 3, p[3]);
-    commit_scales(kt + 1);  // past the last tile: reads of the scale buffer are range-checked
-    load_scales(kt + 2);
+    if constexpr (PREFETCH) rdP(nxt, 0, 3, p[3]);
+    commit_scales(commit_kt);
+    load_scales(st, st_kt);  // past the end of K: reads of the scale buffer are range-checked
     __builtin_amdgcn_sched_barrier(0);
-  }
-  // the trailing zero-fill stages must be out of LDS before the epilogue reuses it
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  };
 
   // ------------------------------------------------------------ epilogue
+  // Wave-private LDS transpose of 16 x 64 fp32 at a time (4 KiB per wave in LDS of its own).
+  // MFMA C layout: lane -> column (lane & 31), register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  // Column index XOR 32 on rows whose bit 2 is set: the two lane halves (rows +4) land 32 banks
+  // apart, so the b32 writes are conflict-free; each b128 read covers 4 rows x 256 contiguous bytes.
+  float *stg = reinterpret_cast<float *>(lds + 2 * kStageBytes) + wave * 1024;
+  const unsigned e_row = lane >> 4;          // 0..3
+  const unsigned e_col = (lane & 15u) * 4u;  // 0..60
   float mult = a.alpha;
   if constexpr (!MX) {
     if (a.sP) mult *= *a.sP;
     if (a.sQ) mult *= *a.sQ;
   }
-  // Wave-private LDS transpose, one 32 x 64 MFMA row block at a time.  Row stride 72 dwords:
-  // the two lane halves (rows +4) land 32 banks apart, so the b32 writes are conflict-free and
-  // each b128 read instruction covers 4 rows x 256 contiguous bytes.
-  constexpr unsigned kStgStride = 72;
-  float *stg = reinterpret_cast<float *>(lds) + wave * (32 * kStgStride);
-  const unsigned e_row = lane >> 4;          // 0..3
-  const unsigned e_col = (lane & 15u) * 4u;  // 0..60
-  const unsigned jbase = j0 + wj * 64 + e_col;
-  auto epilogue = [&](auto *dptr, auto with_c) {
+  // FULL = the tile lies inside D and rows are vector-aligned: no per-element guards (and no
+  // divergent control flow, which would make the compiler drain every store before the next
+  // bias add).  Otherwise the guarded element-wise path.
+  auto epilogue_as = [&](const TileCtx &t, auto *dptr, auto with_c, auto full_tag) {
     using OT = std::remove_pointer_t<decltype(dptr)>;
     constexpr bool WITH_C = decltype(with_c)::value;
+    constexpr bool FULL = decltype(full_tag)::value;
     using VecT = std::conditional_t<sizeof(OT) == 4, u32x4, u32x2>;
-    const bool vec_ok = (a.ldd % 4 == 0) && ((reinterpret_cast<uintptr_t>(dptr) % sizeof(VecT)) == 0) &&
-                        (jbase + 3 < a.m);
+    const unsigned jbase = t.j0 + wj * 64 + e_col;
     float bias[4] = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (jbase + q < a.m) bias[q] = load_any(a.bias, jbase + q, a.bias_dtype);
+      for (int x = 0; x < 4; ++x)
+        if (FULL || jbase + x < a.m) bias[x] = load_any(a.bias, jbase + x, a.bias_dtype);
     }
+    // first (unconditional) use of the bias registers: the wait for their loads happens here, once
+    asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]));
+    // wave-uniform 64-bit base of this wave's 128 x 64 block + a 32-bit lane offset
+    char *wave_base = reinterpret_cast<char *>(dptr + static_cast<size_t>(t.i0 + wi * 128) * a.ldd + t.j0 + wj * 64);
+    const unsigned lane_off = (e_row * a.ldd + e_col) * static_cast<unsigned>(sizeof(OT));
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
+      for (int rh = 0; rh < 2; ++rh) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stg[((r & 3) + 8 * (r >> 2) + 4 * fr_half) * kStgStride + nj * 32 + fr_row] = acc[mi][nj][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const unsigned lr = p * 4 + e_row;
-        const f32x4 t = *reinterpret_cast<const f32x4 *>(stg + lr * kStgStride + e_col);
-        const unsigned i = i0 + wi * 128 + mi * 32 + lr;
-        if (i >= a.n) continue;
-        OT *dst = dptr + static_cast<size_t>(i) * a.ldd + jbase;
-        float v[4] = {t[0] * mult, t[1] * mult, t[2] * mult, t[3] * mult};
-        if (vec_ok) {
-          if constexpr (WITH_C) {
-            OT old[4];
-            *reinterpret_cast<VecT *>(old) = *reinterpret_cast<const VecT *>(dst);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] += a.beta * widen(old[q]);
+          for (int rr = 0; rr < 8; ++rr) {
+            const unsigned l = (rr & 3) + 8 * (rr >> 2) + 4 * fr_half;
+            stg[l * 64 + ((nj * 32 + fr_row) ^ (32u * fr_half))] = acc[mi][nj][8 * rh + rr];
           }
-          OT o[4];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int q = 0; q < 4; ++q) narrow(v[q] + bias[q], o[q]);
-          *reinterpret_cast<VecT *>(dst) = *reinterpret_cast<const VecT *>(o);
-        } else {
+        for (int ps = 0; ps < 4; ++ps) {
+          const unsigned l = ps * 4 + e_row;
+          const f32x4 v4 = *reinterpret_cast<const f32x4 *>(stg + l * 64 + (e_col ^ (32u * (ps & 1))));
+          const unsigned li = mi * 32 + rh * 16 + l;  // row inside this wave's 128
+          OT *dst = reinterpret_cast<OT *>(wave_base + static_cast<size_t>(mi * 32 + rh * 16 + ps * 4) * a.ldd * sizeof(OT) + lane_off);
+          float v[4] = {v4[0] * mult, v4[1] * mult, v4[2] * mult, v4[3] * mult};
+          if constexpr (FULL) {
+            if constexpr (WITH_C) {
+              OT old[4];
+              *reinterpret_cast<VecT *>(old) = *reinterpret_cast<const VecT *>(dst);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (jbase + q >= a.m) continue;
-            float x = v[q];
-            if constexpr (WITH_C) x += a.beta * widen(dst[q]);
-            narrow(x + bias[q], dst[q]);
+              for (int x = 0; x < 4; ++x) v[x] += a.beta * widen(old[x]);
+            }
+            OT o[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) narrow(v[x] + bias[x], o[x]);
+            *reinterpret_cast<VecT *>(dst) = *reinterpret_cast<const VecT *>(o);
+          } else {
+            if (t.i0 + wi * 128 + li >= a.n) continue;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              if (jbase + x >= a.m) continue;
+              float y = v[x];
+              if constexpr (WITH_C) y += a.beta * widen(dst[x]);
+              narrow(y + bias[x], dst[x]);
+            }
           }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   };
-  const bool with_c = a.beta != 0.f;
-  switch (a.d_dtype) {
-    case kNVTEFloat32:
-      with_c ? epilogue(static_cast<float *>(a.D), std::true_type{}) : epilogue(static_cast<float *>(a.D), std::false_type{});
-      break;
-    case kNVTEBFloat16:
-      with_c ? epilogue(static_cast<bf16_t *>(a.D), std::true_type{}) : epilogue(static_cast<bf16_t *>(a.D), std::false_type{});
-      break;
-    default:
-      with_c ? epilogue(static_cast<f16_t *>(a.D), std::true_type{}) : epilogue(static_cast<f16_t *>(a.D), std::false_type{});
-      break;
+  auto epilogue_typed = [&](const TileCtx &t, auto *dptr) {
+    using OT = std::remove_pointer_t<decltype(dptr)>;
+    const bool full = t.i0 + BM <= a.n && t.j0 + BN <= a.m && a.ldd % 4 == 0 &&
+                      reinterpret_cast<uintptr_t>(dptr) % (4 * sizeof(OT)) == 0;
+    const bool with_c = a.beta != 0.f;
+    if (full) {
+      with_c ? epilogue_as(t, dptr, std::true_type{}, std::true_type{}) : epilogue_as(t, dptr, std::false_type{}, std::true_type{});
+    } else {
+      with_c ? epilogue_as(t, dptr, std::true_type{}, std::false_type{}) : epilogue_as(t, dptr, std::false_type{}, std::false_type{});
+    }
+  };
+  auto epilogue = [&](const TileCtx &t) {
+    switch (a.d_dtype) {
+      case kNVTEFloat32: epilogue_typed(t, static_cast<float *>(a.D)); break;
+      case kNVTEBFloat16: epilogue_typed(t, static_cast<bf16_t *>(a.D)); break;
+      default: epilogue_typed(t, static_cast<f16_t *>(a.D)); break;
+    }
+  };
+
+  // ------------------------------------------------------------ the walk over output tiles
+  unsigned tile = blockIdx.x;
+  TileCtx cur_t = make_tile(tile, true);
+
+  // prologue: K tiles 0 and 1 of the first output tile in flight (K tile 1 is an all-zero fill
+  // when nk == 1; the host then launches one workgroup per output tile)
+  stage(cur_t, 0, 0);
+  load_scales(cur_t, 0);
+  stage(cur_t, 1, BK);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  commit_scales(0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  auto first_fragments = [&](unsigned slot) {
+    rdP(slot, 0, 0, p[0]);
+    rdQ(slot, 0, 0, q[0][0]);
+    rdQ(slot, 0, 1, q[0][1]);
+    rdP(slot, 0, 1, p[1]);
+    rdP(slot, 0, 2, p[2]);
+    rdP(slot, 0, 3, p[3]);
+  };
+  first_fragments(0);
+  load_scales(cur_t, 1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  unsigned g = 0;
+  while (true) {
+    const unsigned next = tile + gridDim.x;
+    const bool has_next = next < a.ntiles;
+    const TileCtx next_t = make_tile(next, has_next);
+    for (unsigned kt = 0; kt + 2 < nk; ++kt, ++g) k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, std::true_type{});
+    if (nk >= 2) {
+      k_tile(g, next_t, 0, 0, nk - 1, std::true_type{});
+      ++g;
+    }
+    // the last K tile leaves the fragment registers dead, so the epilogue has room to work in
+    k_tile(g, next_t, BK, 1, 0, std::false_type{});
+    ++g;
+    epilogue(cur_t);
+    if (!has_next) break;
+    first_fragments(g & 1u);
+    zero_acc();
+    tile = next;
+    cur_t = next_t;
   }
+  // the trailing zero-fill stages must be out of LDS before the workgroup ends
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 template <bool MX>
 void launch_by_format(int fa, int fb, const GemmArgs &args, hipStream_t stream) {
-  const dim3 grid(args.ntiles), block(kThreads);
+  const dim3 grid(args.grid), block(kThreads);
 #define TE_GEMM_CASE(A_, B_)                                                                       \
   if (fa == A_ && fb == B_) {                                                                      \
     hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX>), grid, block, 0, stream, args);              \
@@ -616,6 +680,10 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   g.d_dtype = D.data.dtype;
   g.tiles_j = static_cast<unsigned>(ceil_div(m, BN));
   g.ntiles = static_cast<unsigned>(ceil_div(n, BM)) * g.tiles_j;
+  // Persistent launch: one workgroup per CU walks the tile list; a K of a single tile cannot
+  // pipeline across output tiles, so it gets one workgroup per tile.
+  const unsigned cus = static_cast<unsigned>(device_info().num_cus);
+  g.grid = (k > BK) ? std::min(g.ntiles, cus) : g.ntiles;
   if (mx)
     launch_by_format<true>(fmt_of(opB.dtype), fmt_of(opA.dtype), g, stream);
   else
