@@ -157,3 +157,56 @@ def test_gemm_rejects_bad_k():
     X, _ = _int_fp8_tensor((64, 40), E4, 2)
     with pytest.raises(NVTEError, match="Leading dimension requirement"):
         general_gemm(W, X, out_dtype=torch.float32, layout="TN")
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (4352, 4352, 256),    # 17 x 17 = 289 tiles > 256 CUs: some workgroups walk two tiles; 2 K tiles
+    (4400, 4200, 144),    # ragged edge tiles on both sides, 306 tiles, K tail inside the 2nd K tile
+    (8192, 4608, 384),    # 576 tiles: 2-3 tiles per workgroup, odd number (3) of K tiles
+    (5000, 5000, 128),    # single K tile: one workgroup per tile path, 400 tiles
+])
+def test_gemm_exact_persistent_multi_tile(M, N, K):
+    """The persistent kernel pipelines K tiles across output-tile boundaries; small-integer data
+    makes every product and sum exact, so any slip of a slot, tile or fragment shows as a
+    mismatch.  Reference computed on the GPU in fp64 (exact for these magnitudes)."""
+    W, w = _int_fp8_tensor((N, K), E4, 11, lo=-3, hi=4)
+    X, x = _int_fp8_tensor((M, K), E5, 12, lo=-3, hi=4)
+    y, *_ = general_gemm(W, X, out_dtype=torch.float32, layout="TN")
+    bias = torch.arange(N, device="cuda", dtype=torch.float32) % 7
+    yb, *_ = general_gemm(W, X, out_dtype=torch.bfloat16, layout="TN", bias=bias.to(torch.bfloat16))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(x).cuda().double() @ torch.from_numpy(w).cuda().double().T
+    assert torch.equal(y.double(), ref)
+    # bf16 output: |values| <= 9 * K + 6 are integers; exact in bf16 only below 256, so compare rounded
+    assert torch.equal(yb.float(), (ref + bias.double()).float().to(torch.bfloat16).float())
+
+
+def test_gemm_full_size_configs1_against_gpu_matmul():
+    """BASELINE configs[1] sizes (the bench workload): fprop / dgrad / wgrad of the 4096 -> 14336
+    Linear on 8192 tokens, checked against torch.matmul of the dequantized operands in fp32 on the
+    GPU (independent code path; the CPU oracle would take minutes at this size).
+    Tolerance: rtol 1.6e-2 (bf16 output rounding 2^-8 plus FP8-MFMA accumulation) and
+    atol 1e-3 * max|ref| (measured MFMA accumulation error ~2e-5 * absmax per 256 of K)."""
+    tok, hid, ffn = 8192, 4096, 14336
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn(tok, hid, device="cuda", dtype=torch.bfloat16, generator=g)
+    w = (torch.randn(ffn, hid, device="cuda", dtype=torch.float32, generator=g) * 0.02).to(torch.bfloat16)
+    dy = (torch.randn(tok, ffn, device="cuda", dtype=torch.float32, generator=g) * 0.01).to(torch.bfloat16)
+    qx, qw, qg = (Float8CurrentScalingQuantizer(E4, device="cuda"), Float8CurrentScalingQuantizer(E4, device="cuda"),
+                  Float8CurrentScalingQuantizer(E5, device="cuda"))
+    x8, w8, dy8 = qx(x), qw(w), qg(dy)
+    # dequantize with torch's own FP8 decode, not with this library
+    deq = lambda t, td: t._data.view(td).to(torch.float32) * t._scale_inv
+    xf, wf, dyf = deq(x8, torch.float8_e4m3fn), deq(w8, torch.float8_e4m3fn), deq(dy8, torch.float8_e5m2)
+    old = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        for layout, a, b, ref in (("TN", w8, x8, xf @ wf.T), ("NN", w8, dy8, dyf @ wf), ("NT", x8, dy8, dyf.T @ xf)):
+            out, *_ = general_gemm(a, b, out_dtype=torch.bfloat16, layout=layout)
+            torch.cuda.synchronize()
+            err = (out.float() - ref).abs()
+            bound = 1.6e-2 * ref.abs() + 1e-3 * ref.abs().max()
+            assert bool((err <= bound).all()), (layout, float(err.max()), float(ref.abs().max()))
+            del out, ref, err, bound
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = old
