@@ -48,7 +48,8 @@ constexpr int BN = 256;   // tile cols   (index j, rows of Q)
 constexpr int BK = 128;   // bytes of K per stage
 constexpr int kThreads = 512;
 constexpr int kStageBytes = (BM + BN) * BK;  // 64 KiB
-constexpr int kEpilogueBytes = 32 * 1024;    // 8 waves x 4 KiB transpose staging
+constexpr int kEpilogueBytes = 32 * 1024;    // 8 waves x 4 KiB transpose staging (MX: 2 KiB each)
+constexpr int kScaleSlotBytes = 2048;        // MX: e8m0 scale dwords of one K tile, 256 P rows + 256 Q rows
 constexpr unsigned kOOB = 0x80000000u;
 
 struct GemmArgs {
@@ -130,7 +131,11 @@ __device__ __forceinline__ float load_any(const void *p, size_t idx, int dtype) 
 //    two pipeline slots stay live) so that global stores are full 128/256-byte row segments.
 template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * kStageBytes + kEpilogueBytes];
+  // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
+  constexpr int kScaleBase = 2 * kStageBytes;
+  constexpr int kEpiBase = kScaleBase + (MX ? 2 * kScaleSlotBytes : 0);
+  constexpr int kEpiRows = MX ? 8 : 16;  // rows per transpose pass (x 64 fp32 columns per wave)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kEpiBase + 8 * kEpiRows * 256];
   typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
   const unsigned tid = threadIdx.x;
@@ -140,6 +145,12 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   const unsigned tiles_i = (a.n + BM - 1) / BM;
   const unsigned nk = (a.k + BK - 1) / BK;
 
+  // MX: the scale buffer this wave stages (P's for waves 0-3, Q's for waves 4-7)
+  const uint8_t *e_base = wave < 4 ? a.eP : a.eQ;
+  const unsigned e_bytes = wave < 4 ? a.eP_bytes : a.eQ_bytes;
+  const unsigned e_stride = wave < 4 ? a.eP_stride : a.eQ_stride;
+  const bool e_swz = (wave < 4 ? a.eP_swz : a.eQ_swz) != 0;
+
   // Everything that changes from one output tile to the next (all wave-uniform).  The buffer
   // descriptors cover exactly the tile's rows: rows past the matrix end and explicit kOOB
   // offsets read as zero; an invalid tile (past the end of this workgroup's list) gets empty
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     uint8_t *pbase, *qbase;      // first row of the tile in P / Q
     unsigned pbytes, qbytes;     // bytes the tile's descriptors may touch (0 = everything reads 0)
     unsigned i0, j0;
-    unsigned sbP[4], sbQ[2];  // MX: scalar part of the scale addresses
+    unsigned ss;                 // MX: scalar part of this wave's scale source address (K tile 0)
   };
   auto make_tile = [&](unsigned tile, bool valid) {
     TileCtx t;
@@ -163,16 +174,10 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     t.pbytes = rows_p * a.k;
     t.qbytes = rows_q * a.k;
     if constexpr (MX) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const unsigned row0 = t.i0 + wi * 128 + mi * 32;  // multiple of 32
-        t.sbP[mi] = a.eP_swz ? (row0 / 128) * (a.eP_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eP_stride;
-      }
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const unsigned row0 = t.j0 + wj * 64 + nj * 32;
-        t.sbQ[nj] = a.eQ_swz ? (row0 / 128) * (a.eQ_stride / 4) * 512 + ((row0 % 128) / 32) * 4 : row0 * a.eQ_stride;
-      }
+      // this wave stages the scales of tile rows (wave & 3) * 64 .. + 63 of P (waves 0-3) or Q (4-7)
+      const unsigned tile_row0 = wave < 4 ? t.i0 : t.j0;
+      t.ss = e_swz ? ((tile_row0 / 128 + ((wave & 3u) >> 1)) * (e_stride / 4)) * 512 + (wave & 1u) * 256
+                   : (tile_row0 + (wave & 3u) * 64) * e_stride;
     }
     return t;
   };
@@ -254,46 +259,64 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   };
   zero_acc();
 
-  // MX scales: one dword = the 4 K blocks of a K tile for one row (scX current, nxX in flight).
-  // The descriptors cover exactly the scale buffers, so rows of a partial tile that lie past
-  // the (padded) buffer read 0; rows past n / m inside the padding only feed outputs that are
-  // never stored.  Lane part of the address in one VGPR, row block + K tile in the scalar offset.
+  // MX scales: one dword = the 4 K blocks (e8m0 bytes) of a K tile for one row.  They travel
+  // like the payload: wave w copies the dwords of 64 tile rows global -> LDS (one 4-byte LDS-DMA
+  // instruction per K tile) into the scale slot of the K tile, and after the barrier every wave
+  // picks the 6 dwords of its own MFMA rows out of LDS.  The descriptors cover exactly the scale
+  // buffers: rows of a partial tile past the (padded) buffer read 0, rows past n / m inside the
+  // padding only feed outputs that are never stored.
+  //   compact layout  : source row*stride + 4 kt,              LDS image [row]            (dwords)
+  //   swizzled layout : source 512-byte blocks of 128 rows,     LDS image [row/128][row%32][row%128/32]
   uint32_t scP[4] = {0, 0, 0, 0}, scQ[2] = {0, 0};
-  uint32_t nxP[4] = {0, 0, 0, 0}, nxQ[2] = {0, 0};
-  __amdgpu_buffer_rsrc_t re_p, re_q;
-  unsigned svP = 0, svQ = 0, sstepP = 0, sstepQ = 0;
+  unsigned sv = 0, rsP0 = 0, rsQ0 = 0, rsPstep = 0, rsQstep = 0;
   if constexpr (MX) {
-    re_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eP), 0, a.eP_bytes, 0x00020000);
-    re_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.eQ), 0, a.eQ_bytes, 0x00020000);
-    sstepP = a.eP_swz ? 512u : 4u;
-    sstepQ = a.eQ_swz ? 512u : 4u;
-    svP = a.eP_swz ? fr_row * 16 : fr_row * a.eP_stride;
-    svQ = a.eQ_swz ? fr_row * 16 : fr_row * a.eQ_stride;
+    sv = e_swz ? lane * 4 : lane * e_stride;
+    if (a.eP_swz) {
+      rsP0 = wi * 512 + fr_row * 16;
+      rsPstep = 4;
+    } else {
+      rsP0 = (wi * 128 + fr_row) * 4;
+      rsPstep = 128;
+    }
+    if (a.eQ_swz) {
+      rsQ0 = 1024 + (wj >> 1) * 512 + fr_row * 16 + (wj & 1u) * 8;
+      rsQstep = 4;
+    } else {
+      rsQ0 = 1024 + (wj * 64 + fr_row) * 4;
+      rsQstep = 128;
+    }
   }
-  auto load_scales = [&](const TileCtx &t, unsigned kt) {
+  auto stage_scales = [&](const TileCtx &t, unsigned slot, unsigned kt) {
     if constexpr (MX) {
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-        nxP[mi] = __builtin_amdgcn_raw_buffer_load_b32(re_p, svP, t.sbP[mi] + kt * sstepP, 0);
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
-        nxQ[nj] = __builtin_amdgcn_raw_buffer_load_b32(re_q, svQ, t.sbQ[nj] + kt * sstepQ, 0);
+      const __amdgpu_buffer_rsrc_t re =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(e_base), 0, e_bytes, 0x00020000);
+      lds_u8 *dst = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + wave * 256);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4, sv,
+                                               t.ss + kt * (e_swz ? 512u : 4u), 0, 0);
     }
   };
-  // Pre-shift so that opsel 0 / 2 pick this lane's K block.  K blocks past the end of K carry
-  // whatever the padded scale buffer holds: force 2^0 there (their payload bytes are
-  // zero-filled).  Branch-free on purpose: a branch in the main loop lets the optimiser sink
-  // the MFMAs out of their place in the pipeline.
-  auto commit_scales = [&](unsigned kt) {
+  // Pick this wave's scale dwords of K tile `kt` (already in scale slot `slot`) and pre-shift so
+  // that opsel 0 / 2 select this lane's K block.  K blocks past the end of K carry whatever the
+  // padded scale buffer holds: force 2^0 there (their payload bytes are zero-filled).
+  // Branch-free on purpose: a branch in the main loop lets the optimiser sink the MFMAs out of
+  // their place in the pipeline.
+  auto commit_scales = [&](unsigned slot, unsigned kt) {
     if constexpr (MX) {
+      const uint8_t *img = lds + kScaleBase + slot * kScaleSlotBytes;
       const unsigned kbase = min(kt * BK, a.k);
       const unsigned valid = min(4u, (a.k - kbase + 31) / 32);
       const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * valid)) - 1u);
       const uint32_t fill = 0x7F7F7F7Fu & ~keep;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) scP[mi] = ((nxP[mi] & keep) | fill) >> (8 * fr_half);
+      for (int mi = 0; mi < 4; ++mi) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t *>(img + rsP0 + mi * rsPstep);
+        scP[mi] = ((raw & keep) | fill) >> (8 * fr_half);
+      }
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) scQ[nj] = ((nxQ[nj] & keep) | fill) >> (8 * fr_half);
+      for (int nj = 0; nj < 2; ++nj) {
+        const uint32_t raw = *reinterpret_cast<const uint32_t *>(img + rsQ0 + nj * rsQstep);
+        scQ[nj] = ((raw & keep) | fill) >> (8 * fr_half);
+      }
     }
   };
   // one MFMA: acc[mi][nj] += P fragment x Q fragment (K step KS selects the scale bytes)
@@ -364,20 +387,20 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     mm(I1{}, I2{}, I1{}, p[2], q[1][1]);
     if constexpr (PREFETCH) rdP(nxt, 0, 2, p[2]);
     stage_rows(st, cur, st_k0, 3, voff);
+    stage_scales(st, cur, st_kt);
     mm(I1{}, I3{}, I0{}, p[3], q[1][0]);
     mm(I1{}, I3{}, I1{}, p[3], q[1][1]);
     if constexpr (PREFETCH) rdP(nxt, 0, 3, p[3]);
-    commit_scales(commit_kt);
-    load_scales(st, st_kt);  // past the end of K: reads of the scale buffer are range-checked
+    commit_scales(nxt, commit_kt);
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // ------------------------------------------------------------ epilogue
-  // Wave-private LDS transpose of 16 x 64 fp32 at a time (4 KiB per wave in LDS of its own).
+  // Wave-private LDS transpose of kEpiRows x 64 fp32 at a time (LDS of its own).
   // MFMA C layout: lane -> column (lane & 31), register r -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
   // Column index XOR 32 on rows whose bit 2 is set: the two lane halves (rows +4) land 32 banks
   // apart, so the b32 writes are conflict-free; each b128 read covers 4 rows x 256 contiguous bytes.
-  float *stg = reinterpret_cast<float *>(lds + 2 * kStageBytes) + wave * 1024;
+  float *stg = reinterpret_cast<float *>(lds + kEpiBase) + wave * (kEpiRows * 64);
   const unsigned e_row = lane >> 4;          // 0..3
   const unsigned e_col = (lane & 15u) * 4u;  // 0..60
   float mult = a.alpha;
@@ -408,21 +431,21 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-      for (int rh = 0; rh < 2; ++rh) {
+      for (int part = 0; part < 32 / kEpiRows; ++part) {
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) {
+          for (int rr = 0; rr < kEpiRows / 2; ++rr) {
             const unsigned l = (rr & 3) + 8 * (rr >> 2) + 4 * fr_half;
-            stg[l * 64 + ((nj * 32 + fr_row) ^ (32u * fr_half))] = acc[mi][nj][8 * rh + rr];
+            stg[l * 64 + ((nj * 32 + fr_row) ^ (32u * fr_half))] = acc[mi][nj][(kEpiRows / 2) * part + rr];
           }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
+        for (int ps = 0; ps < kEpiRows / 4; ++ps) {
           const unsigned l = ps * 4 + e_row;
           const f32x4 v4 = *reinterpret_cast<const f32x4 *>(stg + l * 64 + (e_col ^ (32u * (ps & 1))));
-          const unsigned li = mi * 32 + rh * 16 + l;  // row inside this wave's 128
-          OT *dst = reinterpret_cast<OT *>(wave_base + static_cast<size_t>(mi * 32 + rh * 16 + ps * 4) * a.ldd * sizeof(OT) + lane_off);
+          const unsigned li = mi * 32 + part * kEpiRows + l;  // row inside this wave's 128
+          OT *dst = reinterpret_cast<OT *>(wave_base + static_cast<size_t>(mi * 32 + part * kEpiRows + ps * 4) * a.ldd * sizeof(OT) + lane_off);
           float v[4] = {v4[0] * mult, v4[1] * mult, v4[2] * mult, v4[3] * mult};
           if constexpr (FULL) {
             if constexpr (WITH_C) {
@@ -476,12 +499,16 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // prologue: K tiles 0 and 1 of the first output tile in flight (K tile 1 is an all-zero fill
   // when nk == 1; the host then launches one workgroup per output tile)
   stage(cur_t, 0, 0);
-  load_scales(cur_t, 0);
+  stage_scales(cur_t, 0, 0);
   stage(cur_t, 1, BK);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  commit_scales(0);
+  stage_scales(cur_t, 1, 1);
+  if constexpr (MX)
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  commit_scales(0, 0);
   auto first_fragments = [&](unsigned slot) {
     rdP(slot, 0, 0, p[0]);
     rdQ(slot, 0, 0, q[0][0]);
@@ -491,7 +518,6 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     rdP(slot, 0, 3, p[3]);
   };
   first_fragments(0);
-  load_scales(cur_t, 1);
   __builtin_amdgcn_sched_barrier(0);
 
   unsigned g = 0;
