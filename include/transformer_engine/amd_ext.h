@@ -31,6 +31,21 @@ void nvte_amd_delayed_scaling_after_reduction(const NVTETensor amax_reduction_bu
                                               enum NVTEDType fp8_dtype, float margin,
                                               hipStream_t stream);
 
+/* MXFP8 "transposed columnwise" layout (no counterpart in the reference).
+ * The reference keeps the columnwise-quantized MXFP8 payload in the input's own [rows, cols]
+ * layout and lets cuBLASLt read it as a non-TN operand.  gfx950's MFMA needs K-contiguous
+ * operands, so -- exactly as nvte_is_non_tn_fp8_gemm_supported() == 0 makes per-tensor FP8 callers
+ * keep a transposed copy -- an MXFP8 output tensor can ask nvte_quantize* to store its
+ * columnwise payload transposed:
+ *   columnwise_data       [cols, rows]              (FP8 bytes, blocks of 32 along the LAST dim)
+ *   columnwise_scale_inv  [pad128(cols), pad4(ceil(rows/32))]   (e8m0; GEMM-swizzled if the
+ *                          tensor's with_gemm_swizzled_scales flag is set -- for that flag the
+ *                          bytes are identical to the reference's swizzled columnwise scales)
+ * nvte_cublas_gemm* consume such tensors for the NN / NT layouts (dgrad / wgrad); without the
+ * flag those MXFP8 layouts are rejected.  Default 0 = reference layout. */
+void nvte_amd_set_columnwise_transposed(NVTETensor tensor, int transposed);
+int nvte_amd_get_columnwise_transposed(const NVTETensor tensor);
+
 /* Library identification: "transformerengine_amd <version> gfx950". */
 const char *nvte_amd_version(void);
 

@@ -210,3 +210,46 @@ def test_gemm_full_size_configs1_against_gpu_matmul():
             del out, ref, err, bound
     finally:
         torch.backends.cuda.matmul.allow_tf32 = old
+
+
+@pytest.mark.parametrize("swizzled", [False, True])
+def test_mxfp8_gemm_dgrad_wgrad_layouts(swizzled):
+    """MXFP8 NN (dgrad) and NT (wgrad): contraction over the stored rows, served by the
+    transposed-columnwise extension.  Oracle: matmul of the dequantized COLUMNWISE-quantized
+    operands (reference layout from the oracle), fp32 output tolerance rtol 1e-3 / atol 1e-3 absmax."""
+    M, N, K = 384, 256, 512     # tokens, out features, in features
+    g = np.random.default_rng(7)
+    x = torch.from_numpy(g.standard_normal((M, K), dtype=np.float32)).cuda().to(torch.bfloat16)
+    w = torch.from_numpy(g.standard_normal((N, K), dtype=np.float32) * 0.05).cuda().to(torch.bfloat16)
+    dy = torch.from_numpy(g.standard_normal((M, N), dtype=np.float32) * 0.01).cuda().to(torch.bfloat16)
+    def mk(dt):
+        q = MXFP8Quantizer(dt, rowwise=True, columnwise=True, columnwise_transposed=True)
+        q.optimize_for_gemm = swizzled
+        return q
+    x8, w8, dy8 = mk(E4)(x), mk(E4)(w), mk(E5)(dy)
+    dx, *_ = general_gemm(w8, dy8, out_dtype=torch.float32, layout="NN", grad=True)
+    dw, *_ = general_gemm(x8, dy8, out_dtype=torch.float32, layout="NT", grad=True)
+    torch.cuda.synchronize()
+    bits = lambda t: oracle.float_to_bf16_bits(t.float().cpu().numpy())
+    rx, rw, rdy = oracle.mxfp8(bits(x), oracle.E4M3), oracle.mxfp8(bits(w), oracle.E4M3), oracle.mxfp8(bits(dy), oracle.E5M2)
+    # dgrad: dX = dY (rowwise blocks along N) @ W (columnwise blocks along N)
+    fdy_r = oracle.dequant_mxfp8(rdy["out_row"], oracle.E5M2, rdy["sc_row"], True)
+    fw_c = oracle.dequant_mxfp8(rw["out_col"], oracle.E4M3, rw["sc_col"], False)
+    ref_dx = fdy_r.astype(np.float64) @ fw_c.astype(np.float64)
+    # wgrad: dW = dY^T (columnwise blocks along M) @ X (columnwise blocks along M)
+    fdy_c = oracle.dequant_mxfp8(rdy["out_col"], oracle.E5M2, rdy["sc_col"], False)
+    fx_c = oracle.dequant_mxfp8(rx["out_col"], oracle.E4M3, rx["sc_col"], False)
+    ref_dw = fdy_c.astype(np.float64).T @ fx_c.astype(np.float64)
+    for got, ref in ((dx, ref_dx), (dw, ref_dw)):
+        got = got.cpu().numpy().astype(np.float64)
+        assert got.shape == ref.shape
+        assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max())
+
+
+def test_mxfp8_gemm_rejects_reference_columnwise_layout_loudly():
+    q = MXFP8Quantizer(E4)            # reference layout: columnwise payload not transposed
+    a = q(torch.randn(256, 256, device="cuda", dtype=torch.bfloat16))
+    b = q(torch.randn(256, 256, device="cuda", dtype=torch.bfloat16))
+    from transformer_engine_amd._lib import NVTEError
+    with pytest.raises(NVTEError, match="transposed columnwise"):
+        general_gemm(a, b, out_dtype=torch.float32, layout="NN")

@@ -10,7 +10,7 @@ import torch
 import oracle
 from helpers import FMT, randn_input, to_oracle_input, u8, uniform_input
 from transformer_engine_amd import recipe as te_recipe
-from transformer_engine_amd._lib import api
+from transformer_engine_amd._lib import NVTEError, api
 from transformer_engine_amd.tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer,
                                            MXFP8Quantizer, TensorWrapper, current_stream_ptr,
                                            wrap_plain)
@@ -311,3 +311,35 @@ def test_errors_are_reported_not_fatal():
     with pytest.raises(NVTEError, match="Either rowwise or columnwise output data need to be allocated"):
         api.nvte_quantize(wi.handle, wo.handle, current_stream_ptr())
     wi.destroy(); wo.destroy()
+
+
+@pytest.mark.parametrize("fp8", FP8)
+@pytest.mark.parametrize("rowwise", [True, False])
+@pytest.mark.parametrize("swizzled", [False, True])
+@pytest.mark.parametrize("shape", [(128, 128), (256, 384), (1024, 640)])
+def test_mxfp8_transposed_columnwise_extension(shape, swizzled, rowwise, fp8):
+    """amd_ext.h extension: the columnwise MXFP8 payload stored transposed with (column, block)
+    scales.  Expected bytes = the oracle's (reference-layout) columnwise result, transposed."""
+    rows, cols = shape
+    x = uniform_input(shape, torch.bfloat16, seed=33)
+    q = MXFP8Quantizer(fp8, rowwise=rowwise, columnwise=True, columnwise_transposed=True)
+    q.optimize_for_gemm = swizzled
+    out = q(x)
+    torch.cuda.synchronize()
+    ref = oracle.mxfp8(to_oracle_input(x), FMT[fp8], rowwise, True)
+    assert tuple(out._columnwise_data.shape) == (cols, rows)
+    assert np.array_equal(u8(out._columnwise_data), ref["out_col"].T)
+    nb = rows // 32
+    if swizzled:
+        # identical to the reference's swizzled columnwise scales
+        assert np.array_equal(u8(out._columnwise_scale_inv).reshape(-1), oracle.swizzle_col_scales(ref["sc_col"]))
+    else:
+        assert np.array_equal(u8(out._columnwise_scale_inv)[:cols, :nb], ref["sc_col"][:nb, :cols].T)
+    if rowwise:
+        assert np.array_equal(u8(out._rowwise_data), ref["out_row"])
+    # the flag round-trips through the C API and unaligned shapes are rejected loudly
+    w = out.wrap()
+    assert api.nvte_amd_get_columnwise_transposed(w.handle) == 1
+    w.destroy()
+    with pytest.raises(NVTEError):
+        q(uniform_input((96, 128), torch.bfloat16, seed=1))

@@ -112,39 +112,8 @@ __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
     *reinterpret_cast<u32x2 *>(out_c + (row0 + i) * cols + col0) = v;
   }
 
-  // 8x8 byte transpose as four 4x4 blocks
-  transpose4x4_bytes(q[0][0], q[1][0], q[2][0], q[3][0]);  // rows 0-3, cols 0-3
-  transpose4x4_bytes(q[0][1], q[1][1], q[2][1], q[3][1]);  // rows 0-3, cols 4-7
-  transpose4x4_bytes(q[4][0], q[5][0], q[6][0], q[7][0]);  // rows 4-7, cols 0-3
-  transpose4x4_bytes(q[4][1], q[5][1], q[6][1], q[7][1]);  // rows 4-7, cols 4-7
-  // now q[j][h] = column 4h+j, rows 0-3 ; q[4+j][h] = column 4h+j, rows 4-7
-
-  // LDS image of the transposed tile: row c (128 B) holds the 16 eight-row chunks of
-  // column c; chunk rg sits at slot (rg ^ (c/8)).
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned c = cg * 8 + h * 4 + j;
-      u32x2 v = {q[j][h], q[4 + j][h]};
-      *reinterpret_cast<u32x2 *>(&tile_t[c * kTile + ((rg ^ cg) << 3)]) = v;
-    }
-  }
-  __syncthreads();
-
-  // transposed output: 4 passes, 16 B per thread per pass
-  const unsigned k = t & 7u;  // 16-row chunk of the output row
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const unsigned c = (t >> 3) + 32u * p;
-    const unsigned cgc = c >> 3;
-    u32x4 v = *reinterpret_cast<const u32x4 *>(&tile_t[c * kTile + ((k ^ (cgc >> 1)) << 4)]);
-    if (cgc & 1u) {
-      u32x4 w = {v[2], v[3], v[0], v[1]};
-      v = w;
-    }
-    *reinterpret_cast<u32x4 *>(out_t + (tile_col * kTile + c) * rows + tile_r * kTile + k * 16) = v;
-  }
+  // transposed output through the LDS image (device_utils.h)
+  store_tile_transposed(tile_t, q, t, out_t + (tile_col * kTile) * rows + tile_r * kTile, rows);
 
   if (amax_ptr != nullptr) {
     amax = block_max<kCtThreads / kWave>(amax, red);

@@ -145,6 +145,9 @@ struct Tensor {
   Buf columnwise_scale_inv;
   NVTEScalingMode scaling_mode = NVTE_DELAYED_TENSOR_SCALING;
   bool with_gemm_swizzled_scales = false;
+  // amd_ext.h: the MXFP8 columnwise payload is stored TRANSPOSED ([last, prod(leading)]) with
+  // columnwise scales indexed (column, 32-row block), i.e. as the rowwise form of the transpose.
+  bool columnwise_transposed = false;
   bool row_scaled_nvfp4 = false;  // stored only
   int nvfp4_e4m3_max = 448;       // stored only
   uint32_t slot = 0;              // arena slot (handle - 1)
@@ -160,6 +163,7 @@ struct Tensor {
     columnwise_scale_inv.reset();
     scaling_mode = mode;
     with_gemm_swizzled_scales = false;
+    columnwise_transposed = false;
     row_scaled_nvfp4 = false;
     nvfp4_e4m3_max = 448;
   }

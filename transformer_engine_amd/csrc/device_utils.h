@@ -198,6 +198,45 @@ __device__ __forceinline__ void transpose4x4_bytes(uint32_t &r0, uint32_t &r1, u
   r3 = perm(t3, t1, 0x07060302u);
 }
 
+// Transposed store of a 128x128 FP8 tile held as 8x8 byte blocks by 256 threads: thread t owns
+// rows 8*(t>>4).., columns 8*(t&15).. of the tile; q[i][h] = row i, columns 4h..4h+3.
+// The block is transposed in registers (four 4x4 byte transposes), written as eight
+// ds_write_b64 into a 16 KiB LDS image of the transposed tile (row c = 128 B = 16 eight-row
+// chunks, chunk rg at slot rg ^ (c/8): conflict-free for the 16-lane b64 groups), and after one
+// barrier written out 16 B per thread per pass: one wave instruction = eight full 128-B lines
+// of out_t, whose row c starts at out_t + c * ld.  `q` is clobbered.
+__device__ __forceinline__ void store_tile_transposed(uint8_t *tile_t, uint32_t (&q)[8][2], unsigned t,
+                                                      uint8_t *out_t, size_t ld) {
+  const unsigned cg = t & 15u, rg = t >> 4;
+  transpose4x4_bytes(q[0][0], q[1][0], q[2][0], q[3][0]);  // rows 0-3, cols 0-3
+  transpose4x4_bytes(q[0][1], q[1][1], q[2][1], q[3][1]);  // rows 0-3, cols 4-7
+  transpose4x4_bytes(q[4][0], q[5][0], q[6][0], q[7][0]);  // rows 4-7, cols 0-3
+  transpose4x4_bytes(q[4][1], q[5][1], q[6][1], q[7][1]);  // rows 4-7, cols 4-7
+  // now q[j][h] = column 4h+j, rows 0-3 ; q[4+j][h] = column 4h+j, rows 4-7
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned c = cg * 8 + h * 4 + j;
+      u32x2 v = {q[j][h], q[4 + j][h]};
+      *reinterpret_cast<u32x2 *>(&tile_t[c * 128 + ((rg ^ cg) << 3)]) = v;
+    }
+  }
+  __syncthreads();
+  const unsigned k = t & 7u;  // 16-row chunk of the output row
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned c = (t >> 3) + 32u * p;
+    const unsigned cgc = c >> 3;
+    u32x4 v = *reinterpret_cast<const u32x4 *>(&tile_t[c * 128 + ((k ^ (cgc >> 1)) << 4)]);
+    if (cgc & 1u) {
+      u32x4 w = {v[2], v[3], v[0], v[1]};
+      v = w;
+    }
+    *reinterpret_cast<u32x4 *>(out_t + c * ld + k * 16) = v;
+  }
+}
+
 __device__ __forceinline__ bool noop_set(const float *noop) { return noop != nullptr && noop[0] == 1.0f; }
 
 }  // namespace te

@@ -48,7 +48,6 @@ constexpr int BN = 256;   // tile cols   (index j, rows of Q)
 constexpr int BK = 128;   // bytes of K per stage
 constexpr int kThreads = 512;
 constexpr int kStageBytes = (BM + BN) * BK;  // 64 KiB
-constexpr int kEpilogueBytes = 32 * 1024;    // 8 waves x 4 KiB transpose staging (MX: 2 KiB each)
 constexpr int kScaleSlotBytes = 2048;        // MX: e8m0 scale dwords of one K tile, 256 P rows + 256 Q rows
 constexpr unsigned kOOB = 0x80000000u;
 
@@ -644,23 +643,37 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     NVTE_CHECK(k % 16 == 0, "Leading dimension requirement on A for FP8 GEMM. Caller must pad.");
   } else if (is_mxfp8(A.scaling_mode)) {
     mx = true;
-    // Rowwise data is K-contiguous only for a transposed A / non-transposed B.
-    NVTE_CHECK(transa, "MXFP8 GEMM: non-transposed A (columnwise operand) is not implemented yet");
-    NVTE_CHECK(!transb, "MXFP8 GEMM: transposed B (columnwise operand) is not implemented yet");
-    NVTE_CHECK(A.has_data(), "Input A is missing row-wise usage");
-    NVTE_CHECK(B.has_data(), "Input B is missing row-wise usage");
-    opA.data = static_cast<const uint8_t *>(A.data.ptr);
-    opA.dtype = A.data.dtype;
-    opA.scale_inv = A.scale_inv.ptr;
-    opA.scale_stride = static_cast<unsigned>(A.scale_inv.shape.data[A.scale_inv.shape.ndim - 1]);
-    opA.swizzled = A.with_gemm_swizzled_scales;
-    opA.scale_bytes = A.scale_inv.numel();
-    opB.data = static_cast<const uint8_t *>(B.data.ptr);
-    opB.dtype = B.data.dtype;
-    opB.scale_inv = B.scale_inv.ptr;
-    opB.scale_stride = static_cast<unsigned>(B.scale_inv.shape.data[B.scale_inv.shape.ndim - 1]);
-    opB.swizzled = B.with_gemm_swizzled_scales;
-    opB.scale_bytes = B.scale_inv.numel();
+    // Rowwise data is K-contiguous for a transposed A / non-transposed B.  The other layouts
+    // contract over the stored rows: they need the columnwise-quantized copy in the transposed
+    // layout of amd_ext.h (the MXFP8 twin of "non-TN FP8 GEMM unsupported -> keep a transpose").
+    auto pick = [](const Tensor &T, bool rowwise, const char *name) {
+      Operand op;
+      if (rowwise) {
+        NVTE_CHECK(T.has_data(), "Input ", name, " is missing row-wise usage");
+        op.data = static_cast<const uint8_t *>(T.data.ptr);
+        op.dtype = T.data.dtype;
+        op.scale_inv = T.scale_inv.ptr;
+        op.scale_stride = static_cast<unsigned>(T.scale_inv.shape.data[T.scale_inv.shape.ndim - 1]);
+        op.scale_bytes = T.scale_inv.numel();
+      } else {
+        NVTE_CHECK(T.has_columnwise_data(), "Input ", name, " is missing column-wise usage");
+        NVTE_CHECK(T.columnwise_transposed,
+                   "MXFP8 GEMM: this layout contracts over the stored rows of ", name,
+                   "; quantize it with the transposed columnwise layout "
+                   "(nvte_amd_set_columnwise_transposed) - the un-transposed columnwise payload is "
+                   "not readable by the gfx950 MFMA path");
+        op.data = static_cast<const uint8_t *>(T.columnwise_data.ptr);
+        op.dtype = T.columnwise_data.dtype;
+        op.scale_inv = T.columnwise_scale_inv.ptr;
+        op.scale_stride =
+            static_cast<unsigned>(T.columnwise_scale_inv.shape.data[T.columnwise_scale_inv.shape.ndim - 1]);
+        op.scale_bytes = T.columnwise_scale_inv.numel();
+      }
+      op.swizzled = T.with_gemm_swizzled_scales;
+      return op;
+    };
+    opA = pick(A, transa, "A");
+    opB = pick(B, !transb, "B");
     NVTE_CHECK(is_fp8(opA.dtype) && is_fp8(opB.dtype), "MXFP8 GEMM needs FP8 payloads");
     NVTE_CHECK(opA.scale_inv != nullptr && opB.scale_inv != nullptr,
                "FP8 input to GEMM requires inverse of scale!");

@@ -67,7 +67,9 @@ __host__ __device__ __forceinline__ size_t swizzled_idx(size_t i, size_t j, size
   return tile * 512 + (y % 32) * 16 + (y / 32) * 4 + x;
 }
 
-template <typename IT, Fp8 F, bool ROW, bool COL, bool SWZ>
+// TCOL: store the columnwise payload transposed ([cols, rows]) and its compact scales as
+// [cols, rows/32] (amd_ext.h, nvte_amd_set_columnwise_transposed)
+template <typename IT, Fp8 F, bool ROW, bool COL, bool SWZ, bool TCOL = false>
 __global__ __launch_bounds__(256) void mxfp8_tile_kernel(
     const IT *__restrict__ in, const float *__restrict__ noop, uint8_t *__restrict__ out_row,
     uint8_t *__restrict__ out_col, uint8_t *__restrict__ sc_row, uint8_t *__restrict__ sc_col,
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void mxfp8_tile_kernel(
     const size_t stride_c, const unsigned tiles_c) {
   if (noop_set(noop)) return;
   __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) uint8_t tile_t[TCOL ? kTile * kTile : 16];
   constexpr float rcp_max = 1.0f / Fp8Traits<F>::max_finite;  // correctly rounded constant
 
   const unsigned t = threadIdx.x;
@@ -137,12 +140,21 @@ __global__ __launch_bounds__(256) void mxfp8_tile_kernel(
     for (int i = 0; i < 8; ++i) {
       qc[i][0] = cvt4_fp8<F>(f[i][0], f[i][1], f[i][2], f[i][3]);
       qc[i][1] = cvt4_fp8<F>(f[i][4], f[i][5], f[i][6], f[i][7]);
-      u32x2 q = {qc[i][0], qc[i][1]};
-      *reinterpret_cast<u32x2 *>(out_col + (row0 + i) * cols + col0) = q;
+      if constexpr (!TCOL) {
+        u32x2 q = {qc[i][0], qc[i][1]};
+        *reinterpret_cast<u32x2 *>(out_col + (row0 + i) * cols + col0) = q;
+      }
     }
+    if constexpr (TCOL)
+      store_tile_transposed(tile_t, qc, t, out_col + (tile_col * kTile) * rows + tile_r * kTile, rows);
     if ((t & 63u) < 16u) {  // rg_local == 0 holds the wave's 32-row block scale for 8 columns
       const size_t blk = tile_r * 4 + (t >> 6);
-      if constexpr (SWZ) {
+      if constexpr (TCOL && !SWZ) {
+        // compact scales of the transposed operand: [column][32-row block], stride_c = pad4(rows/32)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          sc_col[(col0 + j) * stride_c + blk] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
+      } else if constexpr (SWZ) {
         const size_t tiles_x = ceil_div_dev(rows, 128);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -278,6 +290,7 @@ void launch_quant(const Tensor &in, const float *noop, Tensor &out, hipStream_t 
   const size_t rows = in.rows(), cols = in.cols();
   const bool row = out.has_data(), col = out.has_columnwise_data();
   const bool swz = out.with_gemm_swizzled_scales;
+  const bool tcol = out.has_columnwise_data() && out.columnwise_transposed;
   const IT *ip = static_cast<const IT *>(in.data.ptr);
   uint8_t *orow = static_cast<uint8_t *>(out.data.ptr);
   uint8_t *ocol = static_cast<uint8_t *>(out.columnwise_data.ptr);
@@ -290,6 +303,9 @@ void launch_quant(const Tensor &in, const float *noop, Tensor &out, hipStream_t 
   const bool fast = rows % kTile == 0 && cols % kTile == 0 && aligned16(ip) &&
                     (!row || (aligned8(orow) && aligned8(srow))) &&
                     (!col || (aligned8(ocol) && aligned8(scol)));
+  NVTE_CHECK(!tcol || (fast && aligned16(ocol)),
+             "MXFP8 transposed-columnwise output needs 128-multiple dims and 16-byte aligned buffers (got ",
+             rows, "x", cols, ")");
   if (fast) {
     const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
     const size_t nblk = (rows / kTile) * tiles_c;
@@ -297,7 +313,16 @@ void launch_quant(const Tensor &in, const float *noop, Tensor &out, hipStream_t 
 #define TE_MX_LAUNCH(R, C, S)                                                                      \
   hipLaunchKernelGGL((mxfp8_tile_kernel<IT, F, R, C, S>), dim3(nblk), dim3(256), 0, stream, ip,   \
                      noop, orow, ocol, srow, scol, amax, rows, cols, stride_r, stride_c, tiles_c)
-    if (row && col) {
+#define TE_MX_LAUNCH_T(R, S)                                                                        \
+  hipLaunchKernelGGL((mxfp8_tile_kernel<IT, F, R, true, S, true>), dim3(nblk), dim3(256), 0, stream, ip, \
+                     noop, orow, ocol, srow, scol, amax, rows, cols, stride_r, stride_c, tiles_c)
+    if (tcol) {
+      if (row) {
+        if (swz) TE_MX_LAUNCH_T(true, true); else TE_MX_LAUNCH_T(true, false);
+      } else {
+        if (swz) TE_MX_LAUNCH_T(false, true); else TE_MX_LAUNCH_T(false, false);
+      }
+    } else if (row && col) {
       if (swz) TE_MX_LAUNCH(true, true, true); else TE_MX_LAUNCH(true, true, false);
     } else if (row) {
       if (swz) TE_MX_LAUNCH(true, false, true); else TE_MX_LAUNCH(true, false, false);
@@ -305,6 +330,7 @@ void launch_quant(const Tensor &in, const float *noop, Tensor &out, hipStream_t 
       if (swz) TE_MX_LAUNCH(false, true, true); else TE_MX_LAUNCH(false, true, false);
     }
 #undef TE_MX_LAUNCH
+#undef TE_MX_LAUNCH_T
   } else {
     const unsigned tiles_c = static_cast<unsigned>(ceil_div(cols, 32));
     const size_t nblk = ceil_div(rows, 32) * tiles_c;
@@ -431,8 +457,16 @@ void mxfp8_quantize_launch(const Tensor &in, const float *noop, Tensor &out, hip
   }
   if (col) {
     NVTE_CHECK(out.columnwise_scale_inv.ptr != nullptr, "Columnwise scaling tensor must be allocated");
-    NVTE_CHECK(same_shape(out.columnwise_data.shape, in.data.shape),
-               "Input and columnwise output shapes need to match.");
+    if (out.columnwise_transposed) {
+      const auto [r, c] = in.flat2d();
+      NVTE_CHECK(out.columnwise_data.numel() == r * c && out.columnwise_data.shape.ndim >= 1 &&
+                     out.columnwise_data.shape.data[0] == c,
+                 "Transposed columnwise output must have shape [", c, ", ", r, "], got ",
+                 out.columnwise_data.shape);
+    } else {
+      NVTE_CHECK(same_shape(out.columnwise_data.shape, in.data.shape),
+                 "Input and columnwise output shapes need to match.");
+    }
   }
   if (in.data.numel() == 0) return;
   const bool e4 = out.dtype() == kNVTEFloat8E4M3;

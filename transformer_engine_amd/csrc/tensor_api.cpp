@@ -152,8 +152,19 @@ NVTEShape Tensor::shape() const {
       }
       return data.shape;
     }
-    case NVTE_MXFP8_1D_SCALING:
+    case NVTE_MXFP8_1D_SCALING: {
+      if (!has_data() && has_columnwise_data() && columnwise_transposed) {
+        // extension layout: stored [last, leading] -> logical [leading, last]
+        NVTEShape out{{0}, 0};
+        const NVTEShape &c = columnwise_data.shape;
+        if (c.ndim > 0) {
+          for (size_t i = 1; i < c.ndim; ++i) out.data[out.ndim++] = c.data[i];
+          out.data[out.ndim++] = c.data[0];
+        }
+        return out;
+      }
       return (!has_data() && has_columnwise_data()) ? columnwise_data.shape : data.shape;
+    }
     default:
       NVTE_ERROR("Cannot parse tensor shape with scaling mode \"", scaling_mode_name(scaling_mode),
                  "\"");
@@ -205,7 +216,8 @@ void check_scale_shapes(const Tensor &t, const char *name) {
                  t.scale_inv.shape, ")");
     }
     if (t.has_columnwise_data()) {
-      const size_t e0 = round_up(ceil_div(r, 32), 4), e1 = round_up(c, 128);
+      const size_t e0 = t.columnwise_transposed ? round_up(c, 128) : round_up(ceil_div(r, 32), 4);
+      const size_t e1 = t.columnwise_transposed ? round_up(ceil_div(r, 32), 4) : round_up(c, 128);
       NVTE_CHECK(shape_is(t.columnwise_scale_inv.shape, e0, e1), "Tensor \"", name,
                  "\" has invalid columnwise_scale_inv shape (expected (", e0, ",", e1, "), got ",
                  t.columnwise_scale_inv.shape, ")");
@@ -320,6 +332,21 @@ int nvte_amd_get_error_mode(void) { return g_error_mode.load(); }
 const char *nvte_amd_last_error(void) { return tl_has_error ? tl_error.c_str() : nullptr; }
 void nvte_amd_clear_error(void) { tl_has_error = false; }
 const char *nvte_amd_version(void) { return "transformerengine_amd 0.1 gfx950"; }
+
+void nvte_amd_set_columnwise_transposed(NVTETensor tensor, int transposed) {
+  api_guard("nvte_amd_set_columnwise_transposed", [&] {
+    Tensor &t = *lookup_checked(tensor);
+    NVTE_CHECK(is_mxfp8(t.scaling_mode) || transposed == 0,
+               "columnwise_transposed is an MXFP8 extension (per-tensor scaling always stores the transpose)");
+    t.columnwise_transposed = transposed != 0;
+  });
+}
+int nvte_amd_get_columnwise_transposed(const NVTETensor tensor) {
+  return api_guard("nvte_amd_get_columnwise_transposed", [&]() -> int {
+    if (tensor == nullptr) return 0;
+    return lookup_checked(tensor)->columnwise_transposed ? 1 : 0;
+  });
+}
 
 NVTETensor nvte_create_tensor(NVTEScalingMode scaling_mode) {
   return api_guard("nvte_create_tensor", [&]() -> NVTETensor {

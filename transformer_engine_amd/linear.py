@@ -85,8 +85,9 @@ class LinearFP8State:
             self.bwd_q = [mk(b) for _ in range(2)]
         elif isinstance(recipe, MXFP8BlockScaling):
             f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
-            self.fwd_q = [MXFP8Quantizer(f) for _ in range(3)]
-            self.bwd_q = [MXFP8Quantizer(b) for _ in range(2)]
+            # columnwise copies in the K-contiguous (transposed) layout the dgrad / wgrad GEMMs read
+            self.fwd_q = [MXFP8Quantizer(f, columnwise_transposed=True) for _ in range(3)]
+            self.bwd_q = [MXFP8Quantizer(b, columnwise_transposed=True) for _ in range(2)]
         else:
             raise TypeError(f"unsupported recipe {type(recipe)}")
         self.weight_cache = None  # quantized weight kept across microbatches

@@ -273,7 +273,8 @@ class MXFP8Tensor:
     ref pytorch/csrc/type_converters.cpp:55-89)."""
 
     def __init__(self, *, shape, dtype, rowwise_data, rowwise_scale_inv, columnwise_data,
-                 columnwise_scale_inv, fp8_dtype, quantizer=None, with_gemm_swizzled_scales=False):
+                 columnwise_scale_inv, fp8_dtype, quantizer=None, with_gemm_swizzled_scales=False,
+                 columnwise_transposed=False):
         self._shape = tuple(shape)
         self.dtype = dtype
         self._rowwise_data = rowwise_data
@@ -283,6 +284,9 @@ class MXFP8Tensor:
         self._fp8_dtype = DType.cast(fp8_dtype)
         self._quantizer = quantizer
         self._with_gemm_swizzled_scales = with_gemm_swizzled_scales
+        # amd_ext.h extension: columnwise payload stored as [last, prod(leading)], scales
+        # [pad128(last), pad4(rows/32)] - what the NN / NT GEMMs (dgrad / wgrad) read
+        self._columnwise_transposed = columnwise_transposed
 
     @property
     def shape(self):
@@ -304,9 +308,12 @@ class MXFP8Tensor:
             w.set_rowwise_data(self._rowwise_data, self._fp8_dtype, self._shape)
             w.set_rowwise_scale_inv(self._rowwise_scale_inv, DType.kFloat8E8M0)
         if self._columnwise_data is not None:
-            w.set_columnwise_data(self._columnwise_data, self._fp8_dtype, self._shape)
+            cshape = tuple(self._columnwise_data.shape) if self._columnwise_transposed else self._shape
+            w.set_columnwise_data(self._columnwise_data, self._fp8_dtype, cshape)
             w.set_columnwise_scale_inv(self._columnwise_scale_inv, DType.kFloat8E8M0)
         w.set_with_gemm_swizzled_scales(self._with_gemm_swizzled_scales)
+        if self._columnwise_transposed:
+            api.nvte_amd_set_columnwise_transposed(w.handle, 1)
         return w
 
     def dequantize(self, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -479,13 +486,18 @@ class MXFP8Quantizer(Quantizer):
     """MXFP8: one e8m0 scale per 32 consecutive elements, rowwise and/or columnwise
     (ref pytorch/tensor/mxfp8_tensor.py:29-160, csrc/quantizer.cpp:1700-1830)."""
 
-    def __init__(self, fp8_dtype, *, rowwise: bool = True, columnwise: bool = True):
+    def __init__(self, fp8_dtype, *, rowwise: bool = True, columnwise: bool = True,
+                 columnwise_transposed: bool = False):
         super().__init__(rowwise=rowwise, columnwise=columnwise)
         self.dtype = DType.cast(fp8_dtype)
         self.optimize_for_gemm = False
+        # extension (include/transformer_engine/amd_ext.h): K-contiguous columnwise copy for the
+        # NN / NT GEMMs; needs 128-multiple dims
+        self.columnwise_transposed = columnwise_transposed
 
     def copy(self):
-        q = MXFP8Quantizer(self.dtype, rowwise=self.rowwise_usage, columnwise=self.columnwise_usage)
+        q = MXFP8Quantizer(self.dtype, rowwise=self.rowwise_usage, columnwise=self.columnwise_usage,
+                           columnwise_transposed=self.columnwise_transposed)
         q.optimize_for_gemm = self.optimize_for_gemm
         return q
 
@@ -503,11 +515,17 @@ class MXFP8Quantizer(Quantizer):
             rd = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
             rsi = torch.zeros(rs, dtype=torch.uint8, device=device)
         if self.columnwise_usage:
-            cd = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
-            csi = torch.zeros(cs, dtype=torch.uint8, device=device)
+            if self.columnwise_transposed:
+                rows, cols = _flat2d(tuple(shape))
+                cd = torch.empty((cols, rows), dtype=torch.uint8, device=device)
+                csi = torch.zeros((cs[1], cs[0]), dtype=torch.uint8, device=device)
+            else:
+                cd = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
+                csi = torch.zeros(cs, dtype=torch.uint8, device=device)
         return MXFP8Tensor(shape=shape, dtype=dtype, rowwise_data=rd, rowwise_scale_inv=rsi,
                            columnwise_data=cd, columnwise_scale_inv=csi, fp8_dtype=self.dtype,
-                           quantizer=self, with_gemm_swizzled_scales=self.optimize_for_gemm)
+                           quantizer=self, with_gemm_swizzled_scales=self.optimize_for_gemm,
+                           columnwise_transposed=self.columnwise_usage and self.columnwise_transposed)
 
     def update_quantized(self, src: torch.Tensor, dst: MXFP8Tensor, *, noop_flag=None):
         src = _check_input(src)
