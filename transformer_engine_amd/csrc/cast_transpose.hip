@@ -35,7 +35,7 @@ struct Load8;
 template <>
 struct Load8<bf16_t> {
   static __device__ __forceinline__ void run(const bf16_t *p, float (&f)[8]) {
-    const u32x4 v = *reinterpret_cast<const u32x4 *>(p);
+    const u32x4 v = ld_stream<u32x4>(p);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       f[2 * k] = __uint_as_float(v[k] << 16);
@@ -48,7 +48,7 @@ template <>
 struct Load8<f16_t> {
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   static __device__ __forceinline__ void run(const f16_t *p, float (&f)[8]) {
-    const h8 v = *reinterpret_cast<const h8 *>(p);
+    const h8 v = ld_stream<h8>(p);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(v[k]);
   }
@@ -57,8 +57,8 @@ struct Load8<f16_t> {
 template <>
 struct Load8<float> {
   static __device__ __forceinline__ void run(const float *p, float (&f)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4 *>(p);
-    const f32x4 b = *reinterpret_cast<const f32x4 *>(p + 4);
+    const f32x4 a = ld_stream<f32x4>(p);
+    const f32x4 b = ld_stream<f32x4>(p + 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       f[k] = a[k];
