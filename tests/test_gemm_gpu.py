@@ -253,3 +253,26 @@ def test_mxfp8_gemm_rejects_reference_columnwise_layout_loudly():
     from transformer_engine_amd._lib import NVTEError
     with pytest.raises(NVTEError, match="transposed columnwise"):
         general_gemm(a, b, out_dtype=torch.float32, layout="NN")
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (1024, 1024, 2048),    # 16 tiles on 256 CUs
+    (8192, 9216, 1152),    # 1152 tiles = 4 full rounds + 128, odd K-tile count (9)
+    (1000, 1100, 1040),    # ragged tiles, K tail inside the last K tile
+])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_gemm_exact_partial_rounds(M, N, K, out_dtype):
+    """Tile counts that leave the last round of the persistent walk partly empty (16 tiles, 4.5
+    rounds, ragged edges), long K.  Small-integer data: exact.  Run twice (state-free launches)."""
+    W, w = _int_fp8_tensor((N, K), E4, 21, lo=-2, hi=3)
+    X, x = _int_fp8_tensor((M, K), E4, 22, lo=-2, hi=3)
+    ref = torch.from_numpy(x).cuda().double() @ torch.from_numpy(w).cuda().double().T
+    for _ in range(2):
+        y, *_ = general_gemm(W, X, out_dtype=out_dtype, layout="TN")
+        torch.cuda.synchronize()
+        assert torch.equal(y.double(), ref.float().to(out_dtype).double())
+    # with accumulate (beta = 1) and bias through the same path
+    acc = torch.ones(M, N, device="cuda", dtype=torch.float32)
+    general_gemm(W, X, layout="TN", out=acc, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(acc.double(), ref + 1.0)

@@ -89,7 +89,7 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
         return out, None, None, extra_output
 
     cfg = api.nvte_create_matmul_config()
-    wbias = None
+    wbias = wws = None
     try:
         if bias is not None and not grad:
             wbias = wrap_plain(bias)
@@ -100,14 +100,29 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
         b8 = C.c_uint8(1 if use_split_accumulator else 0)
         api.nvte_set_matmul_config_attribute(cfg, _lib.kMUseSplitAccumulator, C.byref(b8), 1)
         al, be = C.c_float(alpha), C.c_float(beta)
+        wws = wrap_plain(get_workspace(dev))
         api.nvte_cublas_gemm_v2(int(transa), int(transb), C.byref(al), wa.handle, wb.handle,
-                                C.byref(be), wd.handle, wd.handle, None, cfg, current_stream_ptr())
+                                C.byref(be), wd.handle, wd.handle, wws.handle, cfg, current_stream_ptr())
     finally:
         _lib.raw_lib.nvte_destroy_matmul_config(cfg)
-        for w in (wa, wb, wd, wbias):
+        for w in (wa, wb, wd, wbias, wws):
             if w is not None:
                 w.destroy()
     return out, None, None, extra_output
+
+
+_WORKSPACES = {}
+
+
+def get_workspace(device) -> torch.Tensor:
+    """Per-device GEMM workspace of the size the reference allocates (ref pytorch/cpp_extensions/
+    gemm.py:35-40: 32 MiB + 1 KiB).  This library uses it for the partial sums of split tail tiles."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.empty(32 * 1024 * 1024 + 1024, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
 
 
 def _numel(shape) -> int:
