@@ -9,9 +9,13 @@ N = 1 : BASELINE.json configs[1] - Llama-3-8B MLP Linear 4096 -> 14336, 8192 tok
         GEMM dgrad, GEMM wgrad, recipe step (bwd).  The weight quantize is amortised exactly as
         te.Linear does with is_first_microbatch=False (cached FP8 weight); its stand-alone cost is
         reported in "extra".
-N > 1 : the same Linear tensor-parallel + sequence-parallel over N ranks (column-parallel,
-        FP8 all-gather of the input, reduce-scatter of dgrad, amax all-reduce on RCCL), tokens
-        grow with N (8192 per rank) so per-GPU GEMM work is fixed: "scaling": "weak".
+N > 1 : (default, --parallelism dp) every rank runs that same step on its own 8192 tokens with a
+        full copy of the weight; the path's one real exchange at this level is the delayed-scaling
+        amax all-reduce (MAX over the FP8 group, ref quantization.py:666-674), once per forward
+        and once per backward, on RCCL.  Per-GPU work fixed: "scaling": "weak".
+        --parallelism tp_sp : the Linear tensor-parallel + sequence-parallel over N ranks
+        (column-parallel, FP8 all-gather of the input, reduce-scatter of dgrad, amax all-reduce),
+        tokens grow with N (8192 per rank), also weak scaling (BASELINE configs[3] style).
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region.
 """
@@ -40,6 +44,9 @@ def parse():
     ap.add_argument("--in-features", type=int, default=4096)
     ap.add_argument("--out-features", type=int, default=14336)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--parallelism", choices=["dp", "tp_sp"], default="dp")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one device)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -114,12 +121,17 @@ def cpu_baseline(tokens=4096, K=4096, N=14336):
 
 def main():
     args = parse()
+    if os.environ.get("BENCH_DEBUG_HANG"):   # rehearsal aid: dump all stacks and exit if stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_DEBUG_HANG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -130,13 +142,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     M, K, N = args.tokens, args.in_features, args.out_features
     torch.manual_seed(1234 + rank)
     recipe = DelayedScaling()   # HYBRID, history 1024, "max", margin 0 (reference defaults)
 
-    if world == 1:
+    if world == 1 or args.parallelism == "dp":
         x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
         dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
@@ -149,9 +164,9 @@ def main():
             st.update_bwd()
             return y, dx, dw
 
-        flops_per_step = 6.0 * M * N * K
-        parallelism = "single"
-        global_tokens = M
+        flops_per_step = 6.0 * M * N * K * world     # whole job
+        parallelism = "single" if world == 1 else f"dp{world}"
+        global_tokens = M * world
     else:
         from transformer_engine_amd import distributed as D
         mod = D.ColumnParallelLinearSP(K, N, world, rank, recipe, device=dev)
@@ -208,7 +223,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3

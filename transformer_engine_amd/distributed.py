@@ -58,11 +58,14 @@ def reduce_scatter_along_first_dim(x: torch.Tensor, group=None, async_op: bool =
     assert x.shape[0] % tp == 0, "first dim must divide by the tensor-parallel size"
     if dist.get_backend(group) == "gloo":
         # gloo (CPU rehearsals / single-GPU tests) has no reduce_scatter: all-reduce and slice
-        full = x.contiguous().clone()
+        # (on the host: gloo's own CUDA staging was seen to stall when two ranks share one GPU)
+        full = x.detach().to("cpu", copy=True).contiguous()
+        if full.dtype in (torch.bfloat16, torch.float16):
+            full = full.float()
         dist.all_reduce(full, group=group)
         m = x.shape[0] // tp
         r = dist.get_rank(group)
-        return full[r * m:(r + 1) * m].contiguous(), None
+        return full[r * m:(r + 1) * m].to(device=x.device, dtype=x.dtype).contiguous(), None
     out = torch.empty((x.shape[0] // tp,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     handle = dist.reduce_scatter_tensor(out, x.contiguous(), group=group, async_op=async_op)
     return out, handle

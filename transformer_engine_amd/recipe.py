@@ -125,7 +125,14 @@ def reduce_and_update_fp8_tensors(states: List[DelayedScalingRecipeState], group
         import torch.distributed as dist
         # group=None means the default (world) group, as in torch.distributed
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(contiguous_amax, op=dist.ReduceOp.MAX, group=group)
+            if contiguous_amax.is_cuda and dist.get_backend(group) == "gloo":
+                # CPU rehearsal backend: reduce on the host (gloo's own CUDA staging was seen to
+                # stall when two ranks share one GPU); RCCL reduces the device buffer in place
+                host = contiguous_amax.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+                contiguous_amax.copy_(host)
+            else:
+                dist.all_reduce(contiguous_amax, op=dist.ReduceOp.MAX, group=group)
     fused_amax_and_scale_update_after_reduction(
         contiguous_amax, [s.amax_history for s in states], [s.scale for s in states],
         recipe.amax_compute_algo, states[0].dtype, recipe.margin)
