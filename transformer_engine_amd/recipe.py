@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import api
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantizer,
-                     current_stream_ptr, wrap_plain)
+                     TensorWrapper, current_stream_ptr, wrap_plain)
 
 
 class Format(enum.Enum):
@@ -100,7 +100,8 @@ def fused_amax_and_scale_update_after_reduction(amax_reduction_buffer: torch.Ten
                                                 margin: float) -> None:
     """ref pytorch/csrc/extensions/recipe.cpp:32 (tex.fused_amax_and_scale_update_after_reduction)"""
     n = len(amax_histories)
-    wb = wrap_plain(amax_reduction_buffer)
+    # None = nothing was reduced: the kernel then takes each history's own row 0 as the new amax
+    wb = wrap_plain(amax_reduction_buffer) if amax_reduction_buffer is not None else TensorWrapper()
     whs = [wrap_plain(h) for h in amax_histories]
     wss = [wrap_plain(s) for s in scales]
     H = (C.c_void_p * n)(*[w.handle for w in whs])
@@ -120,19 +121,21 @@ def reduce_and_update_fp8_tensors(states: List[DelayedScalingRecipeState], group
     if not states:
         return
     recipe = states[0].recipe
-    contiguous_amax = torch.cat([s.amax_history[0] for s in states])
-    if recipe.reduce_amax:
-        import torch.distributed as dist
-        # group=None means the default (world) group, as in torch.distributed
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if contiguous_amax.is_cuda and dist.get_backend(group) == "gloo":
-                # CPU rehearsal backend: reduce on the host (gloo's own CUDA staging was seen to
-                # stall when two ranks share one GPU); RCCL reduces the device buffer in place
-                host = contiguous_amax.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
-                contiguous_amax.copy_(host)
-            else:
-                dist.all_reduce(contiguous_amax, op=dist.ReduceOp.MAX, group=group)
+    import torch.distributed as dist
+    # group=None means the default (world) group, as in torch.distributed
+    reduce = (recipe.reduce_amax and dist.is_available() and dist.is_initialized()
+              and dist.get_world_size(group) > 1)
+    # single process: no packed buffer (and no copy kernel) at all
+    contiguous_amax = torch.cat([s.amax_history[0] for s in states]) if reduce else None
+    if reduce:
+        if contiguous_amax.is_cuda and dist.get_backend(group) == "gloo":
+            # CPU rehearsal backend: reduce on the host (gloo's own CUDA staging was seen to
+            # stall when two ranks share one GPU); RCCL reduces the device buffer in place
+            host = contiguous_amax.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+            contiguous_amax.copy_(host)
+        else:
+            dist.all_reduce(contiguous_amax, op=dist.ReduceOp.MAX, group=group)
     fused_amax_and_scale_update_after_reduction(
         contiguous_amax, [s.amax_history for s in states], [s.scale for s in states],
         recipe.amax_compute_algo, states[0].dtype, recipe.margin)
