@@ -90,6 +90,8 @@ def lib() -> ctypes.CDLL:
         L.te_gemm_tn_f32_fast.restype = None
         L.te_gemm_tn_f32_fast.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_size_t,
                                           c.c_size_t, c.c_size_t]
+        L.te_gelu_ref.restype = None
+        L.te_gelu_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_int]
         L.te_colsum_ref.restype = None
         L.te_colsum_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_void_p]
         L.te_oracle_num_threads.restype = c.c_int
@@ -245,6 +247,20 @@ def gemm_tn(P: np.ndarray, Q: np.ndarray, alpha: float = 1.0, beta: float = 0.0,
     else:
         lib().te_gemm_tn_f32_ref(_ptr(P), _ptr(Q), _ptr(out), n, m, k, ctypes.c_float(alpha),
                                  ctypes.c_float(beta))
+    return out
+
+
+def gelu(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().te_gelu_ref(_ptr(x), _ptr(out), x.size, 0)
+    return out
+
+
+def dgelu(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().te_gelu_ref(_ptr(x), _ptr(out), x.size, 1)
     return out
 
 

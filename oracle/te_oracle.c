@@ -410,6 +410,22 @@ void te_colsum_ref(const void *in, int in_dtype, size_t rows, size_t cols, float
     for (size_t j = 0; j < cols; ++j) out[j] += load_in(in, i * cols + j, in_dtype);
 }
 
+/* GEMM activation epilogues: tanh-form GELU and its derivative, ref common/util/math.h:21-24 and
+ * :27-32 (the forms TE's own activation kernels use; the cuBLASLt GELU epilogues the reference
+ * GEMM selects at cublaslt_gemm.cu:650-689 are the same tanh approximation). mode 0 = gelu,
+ * 1 = dgelu. */
+void te_gelu_ref(const float *in, float *out, size_t n, int mode) {
+  for (size_t i = 0; i < n; ++i) {
+    const float x = in[i];
+    if (mode == 0) {
+      out[i] = x * (0.5f + 0.5f * tanhf(x * (0.79788456f + 0.03567741f * x * x)));
+    } else {
+      const float t = tanhf(0.79788456f * x * (1.f + 0.044715f * x * x));
+      out[i] = 0.5f * x * ((1.f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.f + t);
+    }
+  }
+}
+
 int te_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

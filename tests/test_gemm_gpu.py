@@ -276,3 +276,136 @@ def test_gemm_exact_partial_rounds(M, N, K, out_dtype):
     general_gemm(W, X, layout="TN", out=acc, accumulate=True)
     torch.cuda.synchronize()
     assert torch.equal(acc.double(), ref + 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM epilogues (ref common/gemm/cublaslt_gemm.cu:619-689): GELU_AUX[_BIAS], DGELU[_BGRAD], BGRADB,
+# FP8 output with D scale / amax.  Integer-valued operands make the pre-activation exact, so aux
+# and the linear parts are compared bit-for-bit; the activations within the tanhf tolerance written
+# at each assert (device tanhf vs glibc tanhf, both fp32).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 160), (512, 768, 384)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_gemm_gelu_aux_epilogue(M, N, K, with_bias):
+    W, w = _int_fp8_tensor((N, K), E4, 31, scale_inv=0.125, lo=-2, hi=3)
+    X, x = _int_fp8_tensor((M, K), E4, 32, scale_inv=0.25, lo=-2, hi=3)
+    bias = (torch.arange(N, dtype=torch.float32, device="cuda") % 7 - 3) * 0.5 if with_bias else None
+    y, _, aux, _ = general_gemm(W, X, out_dtype=torch.float32, layout="TN", gelu=True, bias=bias)
+    torch.cuda.synchronize()
+    pre = (x @ w.T * 0.03125).astype(np.float32)
+    if with_bias:
+        pre = pre + bias.cpu().numpy()[None, :]
+        assert aux.dtype == torch.float32          # aux dtype = bias dtype (ref csrc/extensions/gemm.cpp:256)
+        assert np.array_equal(aux.cpu().numpy(), pre)
+    else:
+        assert aux.dtype == torch.bfloat16
+        assert np.array_equal(aux.view(torch.int16).cpu().numpy().view(np.uint16), oracle.float_to_bf16_bits(pre))
+    # tolerance: 4 ulp-ish of fp32 around |y| <= ~50
+    assert np.allclose(y.cpu().numpy(), oracle.gelu(pre), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 208, 170)])
+@pytest.mark.parametrize("bgrad_dtype", [None, torch.float32, torch.bfloat16])
+def test_gemm_dgelu_epilogue(M, N, K, bgrad_dtype):
+    # dgrad-shaped: D [M, K'] = dY [M, N] W [N, K'] ; here NN layout with A = W [N, Kp], B = dY [M, N]
+    Kp = K
+    W, w = _int_fp8_tensor((N, Kp), E4, 33, lo=-2, hi=3)
+    dY, dy = _int_fp8_tensor((M, N), E5, 34, lo=-2, hi=3, scale_inv=0.5)
+    g = np.random.default_rng(35)
+    aux_np = g.standard_normal((M, Kp)).astype(np.float32) * 2
+    aux = torch.from_numpy(aux_np).cuda()
+    bias = torch.empty(Kp, dtype=bgrad_dtype, device="cuda") if bgrad_dtype is not None else None
+    out_dtype = bgrad_dtype or torch.float32
+    d, bgrad, aux_back, _ = general_gemm(W, dY, out_dtype=out_dtype, layout="NN", gelu=True, gelu_in=aux,
+                                         grad=True, bias=bias)
+    torch.cuda.synchronize()
+    lin = (dy @ w * 0.5).astype(np.float32)
+    ref = lin * oracle.dgelu(aux_np)
+    got = d.float().cpu().numpy()
+    if out_dtype == torch.float32:
+        assert np.allclose(got, ref, rtol=2e-6, atol=2e-6 * np.abs(lin).max())
+    else:  # bf16 output: one bf16 rounding on top
+        assert np.allclose(got, ref, rtol=2 ** -8, atol=1e-5 * np.abs(lin).max())
+    if bgrad_dtype is None:
+        assert bgrad is None
+    else:
+        assert bgrad.shape == (Kp,) and bgrad.dtype == bgrad_dtype
+        col = ref.astype(np.float64).sum(axis=0)
+        scale = np.abs(ref).sum(axis=0).max()
+        # fp32 atomics in arbitrary order (+ one bf16 rounding of the result)
+        tol = 1e-5 if bgrad_dtype == torch.float32 else 2 ** -7
+        assert np.allclose(bgrad.float().cpu().numpy(), col, rtol=tol, atol=tol * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1008, 200, 330)])
+def test_gemm_bgradb_epilogue(M, N, K):
+    # wgrad NT: A = X [M, K], B = dY [M, N] -> dW [N, K]; bias gradient = sum over tokens of dY
+    X, x = _int_fp8_tensor((M, K), E4, 36)
+    dY, dy = _int_fp8_tensor((M, N), E5, 37, scale_inv=0.5)
+    dw, bgrad, _, _ = general_gemm(X, dY, out_dtype=torch.float32, layout="NT", grad=True,
+                                   bias=torch.empty(N, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    assert np.array_equal(dw.cpu().numpy(), (dy.T @ x * 0.5).astype(np.float32))
+    assert bgrad.shape == (N,)
+    assert np.array_equal(bgrad.cpu().numpy(), (dy.sum(axis=0) * 0.5).astype(np.float32))   # exact: small integers
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 160)])
+@pytest.mark.parametrize("out_fmt", [E4, E5])
+def test_gemm_fp8_output_with_scale_and_amax(M, N, K, out_fmt):
+    from transformer_engine_amd.tensor import Float8Quantizer
+    W, w = _int_fp8_tensor((N, K), E4, 38)
+    X, x = _int_fp8_tensor((M, K), E4, 39)
+    scale = torch.full((1,), 0.375, device="cuda")
+    amax = torch.full((1,), 123.0, device="cuda")       # stale value must be overwritten
+    q = Float8Quantizer(scale, amax, out_fmt)
+    bias = torch.arange(N, dtype=torch.bfloat16, device="cuda") % 5
+    y, *_ = general_gemm(W, X, quantization_params=q, layout="TN", bias=bias)
+    torch.cuda.synchronize()
+    ref = (x @ w.T).astype(np.float32) + bias.float().cpu().numpy()[None, :]
+    assert isinstance(y, Float8Tensor)
+    assert np.array_equal(u8(y._data), oracle.float_to_fp8(ref * np.float32(0.375), FMT[out_fmt]))
+    assert float(amax.item()) == float(np.abs(ref).max())
+    assert float(y._scale_inv.item()) == float(np.float32(1.0) / np.float32(0.375))
+    # columnwise copy = byte transpose of the rowwise payload
+    assert np.array_equal(u8(y._transpose), u8(y._data).T)
+
+
+def test_gemm_unfused_output_quantization_current_scaling():
+    W, w = _int_fp8_tensor((256, 128), E4, 40)
+    X, x = _int_fp8_tensor((256, 128), E4, 41)
+    q = Float8CurrentScalingQuantizer(E4, torch.device("cuda"))
+    y, *_ = general_gemm(W, X, quantization_params=q, layout="TN", out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    ref = (x @ w.T).astype(np.float32)
+    sc = oracle.scale_from_amax(float(np.abs(ref).max()), oracle.E4M3)
+    assert np.array_equal(u8(y._data), oracle.float_to_fp8(ref * sc, oracle.E4M3))
+
+
+def test_mxfp8_gemm_gelu_epilogue():
+    M, N, K = 256, 384, 256
+    x = randn_input((M, K), torch.bfloat16, 42)
+    w = randn_input((N, K), torch.bfloat16, 43, scale=0.1)
+    q = MXFP8Quantizer(E4, columnwise=False)
+    qx, qw = q(x), q(w)
+    y, _, aux, _ = general_gemm(qw, qx, out_dtype=torch.float32, layout="TN", gelu=True)
+    y0, *_ = general_gemm(qw, qx, out_dtype=torch.float32, layout="TN")
+    torch.cuda.synchronize()
+    pre = y0.cpu().numpy()
+    # the plain kernel is the oracle-checked one (test_mxfp8_gemm_TN); the epilogue variant must agree with it
+    assert np.array_equal(aux.view(torch.int16).cpu().numpy().view(np.uint16), oracle.float_to_bf16_bits(pre))
+    assert np.allclose(y.cpu().numpy(), oracle.gelu(pre), rtol=2e-6, atol=2e-6)
+
+
+def test_gemm_epilogue_argument_errors():
+    from transformer_engine_amd import NVTEError
+    from transformer_engine_amd.tensor import Float8Quantizer
+    W, _ = _int_fp8_tensor((64, 32), E4, 1)
+    X, _ = _int_fp8_tensor((64, 32), E4, 2)
+    with pytest.raises(ValueError, match="aux tensor"):
+        general_gemm(W, X, out_dtype=torch.float32, layout="TN", gelu=True, grad=True)
+    q = Float8Quantizer(torch.ones(1, device="cuda"), torch.zeros(1, device="cuda"), E4)
+    with pytest.raises(ValueError, match="Accumulation mode not supported for FP8 output"):
+        general_gemm(W, X, quantization_params=q, layout="TN", accumulate=True)
+    with pytest.raises(ValueError, match="non-zero beta"):
+        general_gemm(W, X, out_dtype=torch.float32, layout="TN", beta=0.5)

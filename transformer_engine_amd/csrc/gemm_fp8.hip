@@ -71,7 +71,27 @@ struct GemmArgs {
   unsigned tiles_j;  // number of tile columns
   unsigned ntiles;
   unsigned grid;     // persistent workgroups (<= ntiles)
+  // extended epilogues (kernel variant EPI = true only)
+  int epi;                // kEpiNone / kEpiGeluAux / kEpiDgelu
+  void *aux;              // [n, m] pre-GELU values: written (GELU_AUX) or read (DGELU)
+  int aux_dtype;
+  const float *d_scale;   // FP8 output: scale (device, null = 1) ...
+  float *d_amax;          // ... and amax of the unscaled output (device, may be null)
+  float *dbias_acc;       // DGELU_BGRAD: fp32 [m] column sums of D (atomics), or null
 };
+
+constexpr int kEpiNone = 0;
+constexpr int kEpiGeluAux = 1;  // aux = pre-activation, D = gelu(aux)
+constexpr int kEpiDgelu = 2;    // D = dgelu(aux) * (alpha P Q^T + beta C)
+
+// tanh-form GELU and its derivative, the forms of ref common/util/math.h:21-32
+__device__ __forceinline__ float gelu_tanh(float x) {
+  return x * (0.5f + 0.5f * tanhf(x * (0.79788456f + 0.03567741f * x * x)));
+}
+__device__ __forceinline__ float dgelu_tanh(float x) {
+  const float t = tanhf(0.79788456f * x * (1.f + 0.044715f * x * x));
+  return 0.5f * x * ((1.f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.f + t);
+}
 
 // XCD-aware, bijective remap of the flat workgroup id: workgroups that share an XCD
 // (id % 8) get a contiguous run of tiles; inside a run tiles are walked in groups of
@@ -113,6 +133,16 @@ __device__ __forceinline__ float load_any(const void *p, size_t idx, int dtype) 
   }
 }
 
+__device__ __forceinline__ void store_any(void *p, size_t idx, int dtype, float v) {
+  switch (dtype) {
+    case kNVTEFloat32: static_cast<float *>(p)[idx] = v; break;
+    case kNVTEBFloat16: narrow(v, static_cast<bf16_t *>(p)[idx]); break;
+    case kNVTEFloat16: narrow(v, static_cast<f16_t *>(p)[idx]); break;
+    case kNVTEFloat8E4M3: static_cast<uint8_t *>(p)[idx] = cvt1_fp8<Fp8::E4M3>(v); break;
+    default: static_cast<uint8_t *>(p)[idx] = cvt1_fp8<Fp8::E5M2>(v); break;
+  }
+}
+
 // Main-loop pipeline:
 //  * every MFMA fragment register is refilled from LDS right after its last use, 5..7 MFMAs
 //    before its next one, so the matrix pipe never waits on LDS; LDS and global->LDS
@@ -128,7 +158,10 @@ __device__ __forceinline__ float load_any(const void *p, size_t idx, int dtype) 
 //    latency of a fresh tile nor the drain of the previous tile's stores is exposed;
 //  * the accumulators leave through a wave-private LDS transpose (its own 32 KiB of LDS, the
 //    two pipeline slots stay live) so that global stores are full 128/256-byte row segments.
-template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX>
+//  * EPI = true is the same kernel with the extended epilogue (GELU / dGELU with the aux matrix,
+//    bias-gradient column sums, FP8 output with amax) - element-wise, off the Linear hot path;
+//    the plain instantiation is untouched by it.
+template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, bool EPI>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
   constexpr int kScaleBase = 2 * kStageBytes;
@@ -483,7 +516,89 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       with_c ? epilogue_as(t, dptr, std::true_type{}, std::false_type{}) : epilogue_as(t, dptr, std::false_type{}, std::false_type{});
     }
   };
+  // Extended epilogue: same LDS transpose, then one guarded element at a time:
+  //   y = alpha * acc (+ beta * C) (+ bias);  GELU_AUX: aux = y, y = gelu(y);
+  //   DGELU: y *= dgelu(aux), column sums for the bias gradient;  FP8 D: amax |y|, y * scale.
+  auto epilogue_ext = [&](const TileCtx &t) {
+    const unsigned jbase = t.j0 + wj * 64 + e_col;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        if (jbase + x < a.m) bias[x] = load_any(a.bias, jbase + x, a.bias_dtype);
+    }
+    const bool fp8_out = a.d_dtype == kNVTEFloat8E4M3 || a.d_dtype == kNVTEFloat8E5M2;
+    const float d_scale = (fp8_out && a.d_scale) ? *a.d_scale : 1.f;
+    float tmax = 0.f;
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int part = 0; part < 32 / kEpiRows; ++part) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+          for (int rr = 0; rr < kEpiRows / 2; ++rr) {
+            const unsigned l = (rr & 3) + 8 * (rr >> 2) + 4 * fr_half;
+            // dynamic mi: copy through a switch-free select (mi loop is not unrolled)
+            float v = 0.f;
+#pragma unroll
+            for (int m2 = 0; m2 < 4; ++m2)
+              if (m2 == mi) v = acc[m2][nj][(kEpiRows / 2) * part + rr];
+            stg[l * 64 + ((nj * 32 + fr_row) ^ (32u * fr_half))] = v;
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < kEpiRows / 4; ++ps) {
+          const unsigned l = ps * 4 + e_row;
+          const f32x4 v4 = *reinterpret_cast<const f32x4 *>(stg + l * 64 + (e_col ^ (32u * (ps & 1))));
+          const unsigned gi = t.i0 + wi * 128 + mi * 32 + part * kEpiRows + l;
+          if (gi >= a.n) continue;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const unsigned gj = jbase + x;
+            if (gj >= a.m) continue;
+            const size_t idx = static_cast<size_t>(gi) * a.ldd + gj;
+            float y = v4[x] * mult;
+            if (a.beta != 0.f) y += a.beta * load_any(a.D, idx, a.d_dtype);
+            y += bias[x];
+            if (a.epi == kEpiGeluAux) {
+              store_any(a.aux, idx, a.aux_dtype, y);
+              y = gelu_tanh(y);
+            } else if (a.epi == kEpiDgelu) {
+              y *= dgelu_tanh(load_any(a.aux, idx, a.aux_dtype));
+              colsum[x] += y;
+            }
+            if (fp8_out) {
+              tmax = fmaxf(tmax, fabsf(y));
+              y *= d_scale;
+            }
+            store_any(a.D, idx, a.d_dtype, y);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if (a.dbias_acc) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        // the 4 lanes that share these columns (lane >> 4 = 0..3) add up first
+        float c = colsum[x];
+        c += __shfl_xor(c, 16);
+        c += __shfl_xor(c, 32);
+        if (e_row == 0 && jbase + x < a.m) atomicAdd(a.dbias_acc + jbase + x, c);
+      }
+    }
+    if (fp8_out && a.d_amax) {
+      tmax = wave_max(tmax);
+      if (lane == 0) atomic_max_nonneg(a.d_amax, tmax);
+    }
+  };
   auto epilogue = [&](const TileCtx &t) {
+    if constexpr (EPI) {
+      epilogue_ext(t);
+      return;
+    }
     switch (a.d_dtype) {
       case kNVTEFloat32: epilogue_typed(t, static_cast<float *>(a.D)); break;
       case kNVTEBFloat16: epilogue_typed(t, static_cast<bf16_t *>(a.D)); break;
@@ -543,12 +658,12 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <bool MX>
+template <bool MX, bool EPI>
 void launch_by_format(int fa, int fb, const GemmArgs &args, hipStream_t stream) {
   const dim3 grid(args.grid), block(kThreads);
 #define TE_GEMM_CASE(A_, B_)                                                                       \
   if (fa == A_ && fb == B_) {                                                                      \
-    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX>), grid, block, 0, stream, args);              \
+    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX, EPI>), grid, block, 0, stream, args);         \
     NVTE_CHECK_HIP(hipGetLastError());                                                             \
     return;                                                                                        \
   }
@@ -561,6 +676,49 @@ void launch_by_format(int fa, int fb, const GemmArgs &args, hipStream_t stream) 
 }
 
 int fmt_of(DType t) { return t == kNVTEFloat8E4M3 ? 0 : 1; }
+
+// BGRADB ("bias gradient of input B", ref cublaslt_gemm.cu:667-669): dbias[i] = sum_k B[i][k]
+// in dequantized units, one wave per row of the [n, k] K-contiguous FP8 operand.
+// scale: per-tensor scale_inv (sc != null) or e8m0 per 32-element block (e != null).
+template <Fp8 F>
+__global__ __launch_bounds__(256) void rowsum_fp8_kernel(const uint8_t *__restrict__ in, unsigned n, unsigned k,
+                                                         const float *sc, const uint8_t *e, unsigned e_stride,
+                                                         unsigned e_swz, void *out, int out_dtype) {
+  const unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (row >= n) return;
+  const uint8_t *src = in + static_cast<size_t>(row) * k;
+  float sum = 0.f;
+  for (unsigned c = lane * 16; c < k; c += 64 * 16) {  // k % 16 == 0
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(src + c);
+    float part = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) part += fp8_to_float<F>(v[w], b);
+    if (e != nullptr) {
+      const unsigned blk = c / 32;
+      const size_t ei = e_swz ? (static_cast<size_t>(row / 128) * (e_stride / 4) + blk / 4) * 512 +
+                                    (row % 32) * 16 + (row % 128 / 32) * 4 + blk % 4
+                              : static_cast<size_t>(row) * e_stride + blk;
+      part *= e8m0_to_float(e[ei]);
+    }
+    sum += part;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) store_any(out, row, out_dtype, sc ? sum * *sc : sum);
+}
+
+// fp32 column sums (DGELU_BGRAD accumulator) -> bias dtype
+__global__ void dbias_convert_kernel(const float *acc, void *out, int out_dtype, unsigned m) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) store_any(out, j, out_dtype, acc[j]);
+}
+
+// ref common/common.cu:21-25 (update_tensor_scale_inv_kernel)
+__global__ void scale_inv_from_scale_kernel(const float *scale, float *scale_inv) {
+  *scale_inv = 1.f / (scale == nullptr ? 1.f : *scale);
+}
 
 // One operand after canonicalisation: a K-contiguous byte matrix [rows, k].
 struct Operand {
@@ -576,7 +734,8 @@ struct Operand {
 
 // D = alpha * op(A) op(B) + beta * D  (+bias).  Names follow the reference's cublas_gemm.
 void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, const Tensor *pre_gelu,
-               bool transa, bool transb, bool grad, float alpha, float beta, hipStream_t stream) {
+               bool transa, bool transb, bool grad, const Tensor *workspace, float alpha, float beta,
+               hipStream_t stream) {
   const auto [A0, A1] = A.flat2d();
   const auto [B0, B1] = B.flat2d();
   const size_t m = transa ? A0 : A1;
@@ -591,19 +750,34 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
              scaling_mode_name(A.scaling_mode), ", B.scaling_mode = ", scaling_mode_name(B.scaling_mode));
   NVTE_CHECK(A.has_data() || A.has_columnwise_data(), "Input A does not hold any data!");
   NVTE_CHECK(B.has_data() || B.has_columnwise_data(), "Input B does not hold any data!");
-  NVTE_CHECK(pre_gelu == nullptr || pre_gelu->data.ptr == nullptr,
-             "GELU / dGELU GEMM epilogues are not implemented in this library (out of the Linear hot path)");
   NVTE_CHECK(D.data.ptr != nullptr, "Output D is not allocated");
   NVTE_CHECK(D.data.numel() == m * n, "Output D has wrong size (expected ", n, "x", m, ", got ",
              D.data.shape, ")");
-  NVTE_CHECK(D.data.dtype == kNVTEFloat32 || D.data.dtype == kNVTEBFloat16 || D.data.dtype == kNVTEFloat16,
-             "GEMM output dtype ", dtype_name(D.data.dtype), " is not supported (FP32/BF16/FP16 only)");
+  const bool fp8_out = is_fp8(D.data.dtype);
+  NVTE_CHECK(fp8_out || is_high_precision(D.data.dtype), "GEMM output dtype ", dtype_name(D.data.dtype),
+             " is not supported (FP32/BF16/FP16/FP8 only)");
+  // Epilogue selection, the table of ref cublaslt_gemm.cu:650-689:
+  //   bias & gelu : grad ? DGELU_BGRAD : GELU_AUX_BIAS      bias : grad ? BGRADB : BIAS
+  //   gelu        : grad ? DGELU : GELU_AUX
   const bool has_bias = bias != nullptr && bias->data.ptr != nullptr;
-  NVTE_CHECK(!(has_bias && grad), "bgrad GEMM epilogue is not implemented: use nvte_quantize_dbias / "
-                                  "nvte_cast_transpose_dbias for the bias gradient");
+  const bool gelu = pre_gelu != nullptr && pre_gelu->data.ptr != nullptr;
+  if (gelu) {
+    NVTE_CHECK(!is_fp8(pre_gelu->data.dtype), "fp8 Aux output for gemm + gelu fusion not supported!");
+    NVTE_CHECK(is_high_precision(pre_gelu->data.dtype), "GELU aux tensor must be FP32/BF16/FP16");
+    NVTE_CHECK(pre_gelu->data.numel() == m * n, "GELU aux tensor has wrong size (expected ", n, "x", m,
+               ", got ", pre_gelu->data.shape, ")");
+  }
   if (has_bias) {
-    NVTE_CHECK(bias->data.numel() == m, "Bias has wrong size (expected ", m, ", got ", bias->data.numel(), ")");
+    // BGRADB reduces operand B over k: one entry per column of the column-major D, i.e. n
+    const size_t want = (grad && !gelu) ? n : m;
+    NVTE_CHECK(bias->data.numel() == want, "Bias has wrong size (expected ", want, ", got ",
+               bias->data.numel(), ")");
     NVTE_CHECK(is_high_precision(bias->data.dtype), "Bias dtype must be FP32/BF16/FP16");
+  }
+  if (fp8_out) {
+    NVTE_CHECK(is_tensor_scaling(D.scaling_mode) && is_tensor_scaling(A.scaling_mode),
+               "FP8 GEMM output is implemented for per-tensor scaling only");
+    NVTE_CHECK(beta == 0.f, "Accumulation mode not supported for FP8 output");
   }
 
   Operand opA, opB;  // opA rows = m (reference A), opB rows = n (reference B)
@@ -695,7 +869,6 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   g.P = opB.data;
   g.Q = opA.data;
   g.D = D.data.ptr;
-  g.bias = has_bias ? bias->data.ptr : nullptr;
   g.bias_dtype = has_bias ? bias->data.dtype : kNVTEFloat32;
   if (mx) {
     g.eP = static_cast<const uint8_t *>(opB.scale_inv);
@@ -723,10 +896,66 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   // pipeline across output tiles, so it gets one workgroup per tile.
   const unsigned cus = static_cast<unsigned>(device_info().num_cus);
   g.grid = (k > BK) ? std::min(g.ntiles, cus) : g.ntiles;
+  const bool bias_in_kernel = has_bias && !grad;
+  const bool dgelu_bgrad = has_bias && grad && gelu;
+  const bool bgradb = has_bias && grad && !gelu;
+  g.bias = bias_in_kernel ? bias->data.ptr : nullptr;
+  const bool ext = gelu || fp8_out;
+  if (ext) {
+    g.epi = gelu ? (grad ? kEpiDgelu : kEpiGeluAux) : kEpiNone;
+    g.aux = gelu ? pre_gelu->data.ptr : nullptr;
+    g.aux_dtype = gelu ? pre_gelu->data.dtype : kNVTEFloat32;
+    if (fp8_out) {
+      g.d_scale = static_cast<const float *>(D.scale.ptr);
+      g.d_amax = static_cast<float *>(D.amax.ptr);
+      if (g.d_amax) NVTE_CHECK_HIP(hipMemsetAsync(g.d_amax, 0, sizeof(float), stream));
+    }
+    if (dgelu_bgrad) {
+      // fp32 column sums by atomics: straight into an fp32 bias, else into the caller's workspace
+      if (bias->data.dtype == kNVTEFloat32) {
+        g.dbias_acc = static_cast<float *>(bias->data.ptr);
+      } else {
+        const size_t ws_bytes = workspace ? workspace->data.numel() * dtype_bits(workspace->data.dtype) / 8 : 0;
+        uintptr_t ws = workspace ? reinterpret_cast<uintptr_t>(workspace->data.ptr) : 0;
+        const uintptr_t ws_al = (ws + 255) & ~static_cast<uintptr_t>(255);
+        NVTE_CHECK(ws != 0 && ws_al - ws + m * sizeof(float) <= ws_bytes,
+                   "DGELU_BGRAD epilogue with a ", dtype_name(bias->data.dtype), " bias gradient needs ",
+                   m * sizeof(float) + 256, " bytes of workspace for the FP32 column sums, got ", ws_bytes);
+        g.dbias_acc = reinterpret_cast<float *>(ws_al);
+      }
+      NVTE_CHECK_HIP(hipMemsetAsync(g.dbias_acc, 0, m * sizeof(float), stream));
+    }
+  }
+  const int fp = fmt_of(opB.dtype), fq = fmt_of(opA.dtype);
   if (mx)
-    launch_by_format<true>(fmt_of(opB.dtype), fmt_of(opA.dtype), g, stream);
+    ext ? launch_by_format<true, true>(fp, fq, g, stream) : launch_by_format<true, false>(fp, fq, g, stream);
   else
-    launch_by_format<false>(fmt_of(opB.dtype), fmt_of(opA.dtype), g, stream);
+    ext ? launch_by_format<false, true>(fp, fq, g, stream) : launch_by_format<false, false>(fp, fq, g, stream);
+
+  if (dgelu_bgrad && bias->data.dtype != kNVTEFloat32) {
+    hipLaunchKernelGGL(dbias_convert_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, stream, g.dbias_acc,
+                       bias->data.ptr, static_cast<int>(bias->data.dtype), static_cast<unsigned>(m));
+    NVTE_CHECK_HIP(hipGetLastError());
+  }
+  if (bgradb) {
+    // operand B as the kernel reads it: [n, k] K-contiguous
+    const dim3 grid(static_cast<unsigned>(ceil_div(n, 4))), block(256);
+    const float *sc = mx ? nullptr : static_cast<const float *>(opB.scale_inv);
+    const uint8_t *e = mx ? static_cast<const uint8_t *>(opB.scale_inv) : nullptr;
+    if (opB.dtype == kNVTEFloat8E4M3)
+      hipLaunchKernelGGL(rowsum_fp8_kernel<Fp8::E4M3>, grid, block, 0, stream, opB.data, g.n, g.k, sc, e,
+                         opB.scale_stride, opB.swizzled ? 1u : 0u, bias->data.ptr, static_cast<int>(bias->data.dtype));
+    else
+      hipLaunchKernelGGL(rowsum_fp8_kernel<Fp8::E5M2>, grid, block, 0, stream, opB.data, g.n, g.k, sc, e,
+                         opB.scale_stride, opB.swizzled ? 1u : 0u, bias->data.ptr, static_cast<int>(bias->data.dtype));
+    NVTE_CHECK_HIP(hipGetLastError());
+  }
+  // ref cublaslt_gemm.cu:785-791
+  if (fp8_out && D.scale_inv.ptr != nullptr) {
+    hipLaunchKernelGGL(scale_inv_from_scale_kernel, dim3(1), dim3(1), 0, stream,
+                       static_cast<const float *>(D.scale.ptr), static_cast<float *>(D.scale_inv.ptr));
+    NVTE_CHECK_HIP(hipGetLastError());
+  }
 }
 
 }  // namespace te
@@ -742,9 +971,10 @@ void nvte_cublas_gemm(const NVTETensor A, const NVTETensor B, NVTETensor D, cons
                       NVTETensor workspace, bool accumulate, bool use_split_accumulator,
                       int math_sm_count, hipStream_t stream) {
   api_guard("nvte_cublas_gemm", [&] {
-    (void)workspace; (void)use_split_accumulator; (void)math_sm_count;
+    (void)use_split_accumulator; (void)math_sm_count;
     gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
-              lookup(pre_gelu_out), transa, transb, grad, 1.f, accumulate ? 1.f : 0.f, stream);
+              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), 1.f, accumulate ? 1.f : 0.f,
+              stream);
   });
 }
 
@@ -753,9 +983,9 @@ void nvte_cublas_gemm_scaled(const NVTETensor A, const NVTETensor B, NVTETensor 
                              bool transb, bool grad, NVTETensor workspace, float alpha, float beta,
                              bool use_split_accumulator, int math_sm_count, hipStream_t stream) {
   api_guard("nvte_cublas_gemm_scaled", [&] {
-    (void)workspace; (void)use_split_accumulator; (void)math_sm_count;
+    (void)use_split_accumulator; (void)math_sm_count;
     gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
-              lookup(pre_gelu_out), transa, transb, grad, alpha, beta, stream);
+              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), alpha, beta, stream);
   });
 }
 
@@ -763,7 +993,6 @@ void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTET
                          const NVTETensor B, const float *beta, const NVTETensor C, NVTETensor D,
                          NVTETensor workspace, NVTEMatmulConfig config, hipStream_t stream) {
   api_guard("nvte_cublas_gemm_v2", [&] {
-    (void)workspace;
     const Tensor &a = *lookup_checked(A);
     const Tensor &b = *lookup_checked(B);
     const Tensor *c = lookup_checked(C);
@@ -786,7 +1015,8 @@ void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTET
       NVTE_CHECK(cfg.epilogue_aux_tensor != nullptr, "Requested epilogue without providing aux tensor.");
       aux = lookup(cfg.epilogue_aux_tensor);
     }
-    gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, *alpha, *beta, stream);
+    gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, lookup(workspace), *alpha, *beta,
+              stream);
   });
 }
 
@@ -796,7 +1026,7 @@ void nvte_multi_tensor_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor
                             bool accumulate, bool use_split_accumulator, int math_sm_count,
                             hipStream_t stream) {
   api_guard("nvte_multi_tensor_gemm", [&] {
-    (void)workspace; (void)use_split_accumulator; (void)math_sm_count;
+    (void)use_split_accumulator; (void)math_sm_count;
     if (num_gemms <= 0) return;
     // Independent GEMMs fanned over the compute-stream pool and joined on `stream`
     // (ref cublaslt_gemm.cu:970-1023).
@@ -807,8 +1037,8 @@ void nvte_multi_tensor_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor
     for (int i = 0; i < num_gemms; ++i) {
       gemm_impl(*lookup_checked(A[i]), *lookup_checked(B[i]), *lookup_checked(D[i]),
                 bias ? lookup(bias[i]) : nullptr, pre_gelu_out ? lookup(pre_gelu_out[i]) : nullptr,
-                transa, transb, grad, 1.f, accumulate ? 1.f : 0.f,
-                nvte_get_compute_stream(i % nvte_get_num_compute_streams()));
+                transa, transb, grad, workspace ? lookup(workspace[i % nvte_get_num_compute_streams()]) : nullptr,
+                1.f, accumulate ? 1.f : 0.f, nvte_get_compute_stream(i % nvte_get_num_compute_streams()));
     }
     for (int s = 0; s < ns; ++s) {
       hipEvent_t e = nvte_get_compute_stream_event(s);

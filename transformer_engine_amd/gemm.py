@@ -17,7 +17,8 @@ import torch
 
 from . import _lib
 from ._lib import api
-from .tensor import Float8Tensor, MXFP8Tensor, TensorWrapper, current_stream_ptr, wrap_plain
+from .tensor import (Float8Quantizer, Float8Tensor, MXFP8Tensor, TensorWrapper, current_stream_ptr,
+                     wrap_plain)
 
 
 def _wrap_operand(t) -> Tuple[TensorWrapper, Tuple[int, ...]]:
@@ -52,51 +53,108 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
                  bulk_overlap: bool = False):
     """GEMM supporting fp8 inputs.  Returns (out, bias_grad, gelu_input, extra_output)."""
     assert layout in ("TN", "NN", "NT"), f"GEMM layout {layout} not supported."
-    if gelu or gelu_in is not None:
-        raise NotImplementedError("GELU epilogues are outside the Linear hot path")
     if ub is not None or ub_type is not None:
         raise NotImplementedError("userbuffers objects do not exist here: use "
                                   "transformer_engine_amd.distributed for comm+GEMM overlap")
-    if quantization_params is not None:
-        raise NotImplementedError("quantized GEMM output is not implemented")
     transa, transb = layout[0] == "T", layout[1] == "T"
     if beta is None:
         beta = 1.0 if accumulate else 0.0
-    if not accumulate:
-        beta = 0.0
+    if not accumulate and beta != 0.0:
+        # ref csrc/extensions/gemm.cpp:195-196
+        raise ValueError("Trying to use non-zero beta while not accumulating into D tensor. "
+                         "Beta has nothing to be applied to.")
 
     wa, a_shape = _wrap_operand(A)
     wb, b_shape = _wrap_operand(B)
     out_shape = gemm_output_shape(a_shape, b_shape, transa, transb)
     dev = A.device
-    if out is None:
+
+    # Output quantization (ref csrc/extensions/gemm.cpp:215-235): fused into the GEMM epilogue only
+    # for a delayed-scaling quantizer over per-tensor-scaled inputs; otherwise GEMM to high
+    # precision, then quantize.
+    fused_q = (isinstance(quantization_params, Float8Quantizer)
+               and (isinstance(A, Float8Tensor) or isinstance(B, Float8Tensor)))
+    unfused_q = quantization_params is not None and not fused_q
+    q_out = None
+    if fused_q:
         if accumulate:
-            raise ValueError("accumulate=True needs an `out` tensor")
-        out = torch.empty(out_shape, dtype=out_dtype or torch.bfloat16, device=dev)
+            raise ValueError("Accumulation mode not supported for FP8 output")
+        q_out = out if isinstance(out, Float8Tensor) else quantization_params.make_empty(
+            out_shape, dtype=out_dtype or torch.bfloat16, device=dev)
+        if q_out._data is None:
+            raise ValueError("quantized GEMM output needs row-wise usage")
+        wd = TensorWrapper(_lib.NVTE_DELAYED_TENSOR_SCALING)
+        wd.set_rowwise_data(q_out._data, quantization_params.dtype, out_shape)
+        wd.set_rowwise_scale_inv(q_out._scale_inv)
+        wd.set_scale(quantization_params.scale).set_amax(quantization_params.amax)
+        hp_out = None
     else:
-        if tuple(out.shape) != tuple(out_shape) and out.numel() != _numel(out_shape):
-            raise ValueError(f"GEMM output has invalid dims (expected {out_shape}, got {tuple(out.shape)})")
-        if not out.is_contiguous():
-            raise ValueError("GEMM output must be contiguous")
-    wd = wrap_plain(out)
+        if out is None or unfused_q:
+            if accumulate:
+                raise ValueError("accumulate=True needs an `out` tensor")
+            hp_out = torch.empty(out_shape, dtype=out_dtype or torch.bfloat16, device=dev)
+        else:
+            hp_out = out
+            if tuple(out.shape) != tuple(out_shape) and out.numel() != _numel(out_shape):
+                raise ValueError(f"GEMM output has invalid dims (expected {out_shape}, got {tuple(out.shape)})")
+            if not out.is_contiguous():
+                raise ValueError("Output tensor is not contiguous.")
+        wd = wrap_plain(hp_out)
+
+    def _finish(result):
+        if fused_q:
+            q_out._transpose_invalid = True
+            if q_out._transpose is not None:
+                q_out._create_transpose()
+            return q_out
+        if unfused_q:
+            return quantization_params.quantize(result, out=out if not isinstance(out, torch.Tensor) else None)
+        return result
 
     # zero-fill when an operand is empty (ref csrc/extensions/gemm.cpp:384-392)
     if _numel(a_shape) == 0 or _numel(b_shape) == 0:
-        if out.numel() and not accumulate:
-            out.zero_()
+        if hp_out is not None and hp_out.numel() and not accumulate:
+            hp_out.zero_()
         for w in (wa, wb, wd):
             w.destroy()
-        return out, None, None, extra_output
+        return (hp_out if hp_out is not None else q_out), None, None, extra_output
 
+    a0, a1 = _flat2d(a_shape)
+    b0, b1 = _flat2d(b_shape)
+    m = a0 if transa else a1
+    n = b1 if transb else b0
+    hp_dtype = hp_out.dtype if hp_out is not None else (out_dtype or torch.bfloat16)
+    bias_grad = gelu_input = None
     cfg = api.nvte_create_matmul_config()
-    wbias = wws = None
+    wbias = wws = waux = None
     try:
         if bias is not None and not grad:
-            wbias = wrap_plain(bias)
+            wbias = wrap_plain(bias.contiguous())
             p = C.c_void_p(wbias.handle)
             api.nvte_set_matmul_config_attribute(cfg, _lib.kMBiasTensor, C.byref(p), C.sizeof(p))
         elif bias is not None and grad:
-            raise NotImplementedError("bgrad GEMM epilogue: use Quantizer + bgrad_quantize instead")
+            # ref csrc/extensions/gemm.cpp:241-245 allocates B.shape[-1] entries of the output dtype.
+            # The entries the epilogue writes: BGRADB -> one per row of op(B) (n); DGELU_BGRAD -> one
+            # per output column (m).
+            bias_grad = torch.empty(m if gelu else n, dtype=hp_dtype, device=dev)
+            wbias = wrap_plain(bias_grad)
+            p = C.c_void_p(wbias.handle)
+            api.nvte_set_matmul_config_attribute(cfg, _lib.kMDBiasTensor, C.byref(p), C.sizeof(p))
+        if gelu:
+            # aux dtype: the bias dtype for FP8 inputs (bf16 without a bias), ref gemm.cpp:256
+            gelu_type = bias.dtype if bias is not None else torch.bfloat16
+            if not grad:
+                gelu_input = torch.empty(out_shape, dtype=gelu_type, device=dev)
+            else:
+                if gelu_in is None:
+                    raise ValueError("Requested epilogue without providing aux tensor.")
+                gelu_input = gelu_in.contiguous()
+            waux = wrap_plain(gelu_input)
+            p = C.c_void_p(waux.handle)
+            api.nvte_set_matmul_config_attribute(cfg, _lib.kMEpilogueAux, C.byref(p), C.sizeof(p))
+            one = C.c_uint8(1)
+            api.nvte_set_matmul_config_attribute(cfg, _lib.kMWithDGELU if grad else _lib.kMWithGELU,
+                                                 C.byref(one), 1)
         b8 = C.c_uint8(1 if use_split_accumulator else 0)
         api.nvte_set_matmul_config_attribute(cfg, _lib.kMUseSplitAccumulator, C.byref(b8), 1)
         al, be = C.c_float(alpha), C.c_float(beta)
@@ -105,10 +163,10 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
                                 C.byref(be), wd.handle, wd.handle, wws.handle, cfg, current_stream_ptr())
     finally:
         _lib.raw_lib.nvte_destroy_matmul_config(cfg)
-        for w in (wa, wb, wd, wbias, wws):
+        for w in (wa, wb, wd, wbias, wws, waux):
             if w is not None:
                 w.destroy()
-    return out, None, None, extra_output
+    return _finish(hp_out), bias_grad, gelu_input, extra_output
 
 
 _WORKSPACES = {}
@@ -116,7 +174,8 @@ _WORKSPACES = {}
 
 def get_workspace(device) -> torch.Tensor:
     """Per-device GEMM workspace of the size the reference allocates (ref pytorch/cpp_extensions/
-    gemm.py:35-40: 32 MiB + 1 KiB).  This library uses it for the partial sums of split tail tiles."""
+    gemm.py:35-40: 32 MiB + 1 KiB).  This library only uses it for the FP32 column sums of the
+    DGELU_BGRAD epilogue."""
     key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None:
