@@ -33,6 +33,16 @@ void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
                                 const NVTEQuantizationConfig quant_config, const size_t num_tensors,
                                 hipStream_t stream);
 
+/* ref cast.h:102.  Grouped quantize: every member tensor of `input` is quantized with ITS entry of
+ * output's per-tensor `scale` array (FP8 per-tensor scaling); rowwise bytes keep the flat layout,
+ * columnwise bytes are each member's transpose at the member's own offset.  Shapes are read on the
+ * device (first_dims / last_dims / tensor_offsets), honours the config's noop flag.  amax and
+ * scale_inv are NOT touched (nvte_group_compute_amax_with_config / _scale_from_amax own them). */
+void nvte_group_quantize(const NVTEGroupedTensor input, NVTEGroupedTensor output,
+                         const NVTEQuantizationConfig quant_config, hipStream_t stream);
+/* ref cast.h:429 */
+void nvte_group_dequantize(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

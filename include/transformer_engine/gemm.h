@@ -70,6 +70,61 @@ void nvte_multi_tensor_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor
 /* ref gemm.h:485.  No handle exists here; kept so callers that pre-warm can still call it. */
 void nvte_cublas_handle_init(void);
 
+/* ---- grouped GEMM (ref gemm.h:60-92, 122-152, 301-468) ---- */
+typedef void *NVTEGroupedMatmulConfig;
+enum NVTEGroupedMatmulConfigAttribute {
+  kNVTEGroupedMatmulConfigAvgM = 0,               /* int64 hint (stored, unused) */
+  kNVTEGroupedMatmulConfigAvgN = 1,               /* int64 hint (stored, unused) */
+  kNVTEGroupedMatmulConfigAvgK = 2,               /* int64 hint (stored, unused) */
+  kNVTEGroupedMatmulConfigSMCount = 3,            /* int: number of CUs to use (0 = all) */
+  kNVTEGroupedMatmulConfigUseSplitAccumulator = 4, /* uint8 (stored; FP32 accumulation always) */
+  kNVTEGroupedMatmulConfigNumAttributes
+};
+/* ref gemm.h:123 */ NVTEGroupedMatmulConfig nvte_create_grouped_matmul_config(void);
+/* ref gemm.h:136 */ void nvte_get_grouped_matmul_config_attribute(NVTEGroupedMatmulConfig config,
+                                                                 enum NVTEGroupedMatmulConfigAttribute attr,
+                                                                 void *buf, size_t size_in_bytes,
+                                                                 size_t *size_written);
+/* ref gemm.h:147 */ void nvte_set_grouped_matmul_config_attribute(NVTEGroupedMatmulConfig config,
+                                                                 enum NVTEGroupedMatmulConfigAttribute attr,
+                                                                 const void *buf, size_t size_in_bytes);
+/* ref gemm.h:152 */ void nvte_destroy_grouped_matmul_config(NVTEGroupedMatmulConfig config);
+
+/* ref gemm.h:312.  Bytes of workspace_setup: the per-group descriptors + tile prefix the device-side
+ * setup kernel writes for the persistent grouped kernel. */
+size_t nvte_get_grouped_gemm_setup_workspace_size(size_t num_tensors);
+/* ref gemm.h:324 */ void nvte_convert_int32_to_int64(const int32_t *src, int64_t *dst, size_t n, hipStream_t stream);
+/* ref gemm.h:337 */ void nvte_convert_int32_to_int64_with_multiplier(const int32_t *src, int64_t *dst, size_t n,
+                                                                    int64_t multiplier, hipStream_t stream);
+/* ref gemm.h:352 */ void nvte_compute_grouped_tensor_offsets(const int64_t *first_dims, int64_t *offsets,
+                                                            size_t n_groups, int64_t last_dim, hipStream_t stream);
+
+/* ref gemm.h:388.  D[i] = alpha[i] * op(A[i]) op(B[i]) + beta[i] * C[i] for every member i, ONE
+ * persistent launch; member shapes are read on the device.  FP8 per-tensor scaling operands
+ * (scale_inv[i] per member), BF16/FP16/FP32 C and D.  C may be NULL (beta is then ignored) or D. */
+void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
+                       const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
+                       const NVTETensor beta, NVTETensor workspace_setup, NVTETensor workspace_cublas,
+                       NVTEGroupedMatmulConfig config, hipStream_t stream);
+/* ref gemm.h:415.  A given as a list of (same-shape or not) per-expert weight tensors. */
+void nvte_grouped_gemm_with_discrete_inputA(const NVTETensor *A_list, size_t num_a_tensors, int transa,
+                                            const NVTEGroupedTensor B, int transb, const NVTEGroupedTensor C,
+                                            NVTEGroupedTensor D, const NVTETensor alpha, const NVTETensor beta,
+                                            NVTETensor workspace_setup, NVTETensor workspace_cublas,
+                                            NVTEGroupedMatmulConfig config, hipStream_t stream);
+/* ref gemm.h:445.  C / D given as lists (per-expert wgrad buffers). */
+void nvte_grouped_gemm_with_discrete_out(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B,
+                                         int transb, const NVTETensor *C_list, size_t num_c_tensors,
+                                         NVTETensor *D_list, size_t num_d_tensors, const NVTETensor alpha,
+                                         const NVTETensor beta, NVTETensor workspace_setup,
+                                         NVTETensor workspace_cublas, NVTEGroupedMatmulConfig config,
+                                         hipStream_t stream);
+/* ref gemm.h:458.  output[row, col] += bias[group(row)][col] */
+void nvte_grouped_bias_add(const NVTEGroupedTensor output, const NVTEGroupedTensor bias, hipStream_t stream);
+/* ref gemm.h:467.  output[row, col] += bias[group(row)][col] * scale[row] */
+void nvte_grouped_scaled_bias_add(const NVTEGroupedTensor output, const NVTEGroupedTensor bias,
+                                  const NVTETensor scale, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,14 @@ void nvte_compute_amax_with_config(const NVTETensor input, NVTETensor output,
 void nvte_compute_scale_from_amax(NVTETensor output, const NVTEQuantizationConfig config,
                                   hipStream_t stream);
 
+/* ref recipe.h:113.  One amax per member tensor of `input` into output's amax buffer (zeroed
+ * first); member shapes come from OUTPUT's device-side metadata. */
+void nvte_group_compute_amax_with_config(const NVTEGroupedTensor input, NVTEGroupedTensor output,
+                                         const NVTEQuantizationConfig config, hipStream_t stream);
+/* ref recipe.h:139.  scale[t] = fp8_max / amax[t] (epsilon / pow2 options), scale_inv[t] = 1 / scale[t]. */
+void nvte_group_compute_scale_from_amax(NVTEGroupedTensor output, const NVTEQuantizationConfig config,
+                                        hipStream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 

@@ -154,6 +154,53 @@ int nvte_is_non_tn_fp8_gemm_supported(void);
 
 /* ref :494 */ void nvte_memset(void *ptr, int value, size_t size_in_bytes, hipStream_t stream);
 
+/* ---- grouped-tensor offsets helpers (ref transformer_engine.h:496-547) ---- */
+/* output[0] = 0, output[i+1] = sum_{j<=i} split_sizes[j] * stride; device int64 arrays. */
+/* ref :509 */ void nvte_splits_to_offsets(const int64_t *split_sizes, int64_t *output, size_t num_splits,
+                                           int64_t stride, hipStream_t stream);
+/* output[i] = sum_{j<i} first_dims[j] * last_dims[j]; int32/int64 1-D tensors, output has N+1 entries. */
+/* ref :527 */ void nvte_splits_to_offsets_2d(const NVTETensor first_dims, const NVTETensor last_dims,
+                                              NVTETensor output, hipStream_t stream);
+/* several scaled inclusive scans of one split_sizes tensor (optional leading zero per output). */
+/* ref :545 */ void nvte_splits_to_offsets_multi(NVTETensor split_sizes, NVTETensor *outputs,
+                                                 const int64_t *strides, const int *include_leading_zero,
+                                                 size_t num_outputs, hipStream_t stream);
+
+/* ---- grouped tensors (ref transformer_engine.h:549-662) ----
+ * A collection of num_tensors matrices with one dtype and scaling mode, stored back to back in
+ * flat 1-D buffers.  first_dims / last_dims / tensor_offsets are DEVICE int64 arrays (absent when
+ * the dimension is uniform; tensor_offsets has num_tensors + 1 entries) and are only ever read on
+ * the device, so every grouped entry point is safe under HIP graph capture. */
+typedef void *NVTEGroupedTensor;
+
+enum NVTEGroupedTensorParam {
+  kNVTEGroupedRowwiseData = 0,
+  kNVTEGroupedColumnwiseData = 1,
+  kNVTEGroupedScale = 2,
+  kNVTEGroupedAmax = 3,
+  kNVTEGroupedRowwiseScaleInv = 4,
+  kNVTEGroupedColumnwiseScaleInv = 5,
+  kNVTEGroupedColumnwiseAmax = 6,
+  kNVTEGroupedFirstDims = 7,
+  kNVTEGroupedLastDims = 8,
+  kNVTEGroupedTensorOffsets = 9,
+  kNVTEGroupedWithGEMMSwizzledScales = 10,
+  kNVTENumGroupedTensorParams
+};
+
+/* ref :589 */ NVTEGroupedTensor nvte_create_grouped_tensor(NVTEScalingMode scaling_mode, size_t num_tensors,
+                                                            NVTEShape logical_shape);
+/* ref :600 */ void nvte_destroy_grouped_tensor(NVTEGroupedTensor tensor);
+/* ref :610 */ void nvte_set_grouped_tensor_param(NVTEGroupedTensor tensor, enum NVTEGroupedTensorParam param,
+                                                  const void *buf, size_t size_in_bytes);
+/* ref :625 */ void nvte_get_grouped_tensor_param(const NVTEGroupedTensor tensor,
+                                                  enum NVTEGroupedTensorParam param, void *buf,
+                                                  size_t size_in_bytes, size_t *size_written);
+/* ref :635 */ size_t nvte_grouped_tensor_num_tensors(const NVTEGroupedTensor tensor);
+/* ref :644 */ NVTEDType nvte_grouped_tensor_type(const NVTEGroupedTensor tensor);
+/* ref :653 */ NVTEScalingMode nvte_grouped_tensor_scaling_mode(const NVTEGroupedTensor tensor);
+/* ref :662 */ NVTEShape nvte_get_grouped_tensor_logical_shape(const NVTEGroupedTensor tensor);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

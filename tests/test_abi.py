@@ -265,3 +265,43 @@ def test_misc_entry_points():
     assert all(pack.tensors[i] for i in range(10))
     api.nvte_tensor_pack_destroy(C.byref(pack))
     assert "gfx950" in _lib.version()
+
+
+def test_grouped_tensor_handles_and_config_host_only():
+    """Grouped-tensor descriptor plumbing needs no GPU (ref transformer_engine.cpp:1147-1365)."""
+    import ctypes as C
+    from transformer_engine_amd import _lib
+    api = _lib.api
+    h = api.nvte_create_grouped_tensor(_lib.NVTE_DELAYED_TENSOR_SCALING, 3, _lib.make_shape([96, 64]))
+    assert h
+    assert api.nvte_grouped_tensor_num_tensors(h) == 3
+    assert api.nvte_grouped_tensor_scaling_mode(h) == _lib.NVTE_DELAYED_TENSOR_SCALING
+    s = api.nvte_get_grouped_tensor_logical_shape(h)
+    assert (s.ndim, s.data[0], s.data[1]) == (2, 96, 64)
+    bt = _lib.NVTEBasicTensor(C.c_void_p(0x1000), _lib.kFloat8E4M3, _lib.make_shape([96 * 64]))
+    api.nvte_set_grouped_tensor_param(h, 0, C.byref(bt), C.sizeof(bt))
+    assert api.nvte_grouped_tensor_type(h) == _lib.kFloat8E4M3
+    got = _lib.NVTEBasicTensor()
+    written = C.c_size_t(0)
+    api.nvte_get_grouped_tensor_param(h, 0, C.byref(got), C.sizeof(got), C.byref(written))
+    assert written.value == C.sizeof(got) and got.data_ptr == 0x1000 and got.shape.data[0] == 96 * 64
+    flag = C.c_uint8(1)
+    api.nvte_set_grouped_tensor_param(h, 10, C.byref(flag), 1)
+    back = C.c_uint8(0)
+    api.nvte_get_grouped_tensor_param(h, 10, C.byref(back), 1, None)
+    assert back.value == 1
+    with pytest.raises(_lib.NVTEError, match="Buffer is too small"):
+        api.nvte_set_grouped_tensor_param(h, 0, C.byref(bt), 4)
+    api.nvte_destroy_grouped_tensor(h)
+    assert api.nvte_grouped_tensor_num_tensors(h) == 0          # dead handle reads as empty
+    with pytest.raises(_lib.NVTEError, match="Number of tensors must be greater than 0"):
+        api.nvte_create_grouped_tensor(0, 0, _lib.make_shape([1, 1]))
+    # grouped matmul config attributes round-trip; setup workspace grows with the member count
+    cfg = api.nvte_create_grouped_matmul_config()
+    v = C.c_int64(4096)
+    api.nvte_set_grouped_matmul_config_attribute(cfg, 0, C.byref(v), 8)
+    r = C.c_int64(0)
+    api.nvte_get_grouped_matmul_config_attribute(cfg, 0, C.byref(r), 8, None)
+    assert r.value == 4096
+    api.nvte_destroy_grouped_matmul_config(cfg)
+    assert api.nvte_get_grouped_gemm_setup_workspace_size(64) > api.nvte_get_grouped_gemm_setup_workspace_size(8) > 0

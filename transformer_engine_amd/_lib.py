@@ -147,6 +147,36 @@ _SIGS = {
     "nvte_multi_tensor_gemm": (_V, [C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                     C.POINTER(_P), _I, _B, _B, _B, C.POINTER(_P), _B, _B, _I, _P]),
     "nvte_cublas_handle_init": (_V, []),
+    # grouped tensors / grouped quantize / grouped GEMM
+    "nvte_splits_to_offsets": (_V, [_P, _P, _SZ, C.c_int64, _P]),
+    "nvte_splits_to_offsets_2d": (_V, [_P, _P, _P, _P]),
+    "nvte_splits_to_offsets_multi": (_V, [_P, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(_I), _SZ, _P]),
+    "nvte_create_grouped_tensor": (_P, [_I, _SZ, NVTEShape]),
+    "nvte_destroy_grouped_tensor": (_V, [_P]),
+    "nvte_set_grouped_tensor_param": (_V, [_P, _I, _P, _SZ]),
+    "nvte_get_grouped_tensor_param": (_V, [_P, _I, _P, _SZ, C.POINTER(_SZ)]),
+    "nvte_grouped_tensor_num_tensors": (_SZ, [_P]),
+    "nvte_grouped_tensor_type": (_I, [_P]),
+    "nvte_grouped_tensor_scaling_mode": (_I, [_P]),
+    "nvte_get_grouped_tensor_logical_shape": (NVTEShape, [_P]),
+    "nvte_group_quantize": (_V, [_P, _P, _P, _P]),
+    "nvte_group_dequantize": (_V, [_P, _P, _P]),
+    "nvte_group_compute_amax_with_config": (_V, [_P, _P, _P, _P]),
+    "nvte_group_compute_scale_from_amax": (_V, [_P, _P, _P]),
+    "nvte_create_grouped_matmul_config": (_P, []),
+    "nvte_get_grouped_matmul_config_attribute": (_V, [_P, _I, _P, _SZ, C.POINTER(_SZ)]),
+    "nvte_set_grouped_matmul_config_attribute": (_V, [_P, _I, _P, _SZ]),
+    "nvte_destroy_grouped_matmul_config": (_V, [_P]),
+    "nvte_get_grouped_gemm_setup_workspace_size": (_SZ, [_SZ]),
+    "nvte_convert_int32_to_int64": (_V, [_P, _P, _SZ, _P]),
+    "nvte_convert_int32_to_int64_with_multiplier": (_V, [_P, _P, _SZ, C.c_int64, _P]),
+    "nvte_compute_grouped_tensor_offsets": (_V, [_P, _P, _SZ, C.c_int64, _P]),
+    "nvte_grouped_gemm": (_V, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nvte_grouped_gemm_with_discrete_inputA": (_V, [C.POINTER(_P), _SZ, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nvte_grouped_gemm_with_discrete_out": (_V, [_P, _I, _P, _I, C.POINTER(_P), _SZ, C.POINTER(_P), _SZ, _P, _P,
+                                                 _P, _P, _P, _P]),
+    "nvte_grouped_bias_add": (_V, [_P, _P, _P]),
+    "nvte_grouped_scaled_bias_add": (_V, [_P, _P, _P, _P]),
     # swizzle.h
     "nvte_swizzle_scaling_factors": (_V, [_P, _P, _P]),
     "nvte_multi_tensor_swizzle_scaling_factors": (_V, [C.POINTER(_P), C.POINTER(_P), _SZ, _P]),

@@ -28,45 +28,6 @@ namespace {
 constexpr int kTile = 128;      // tile edge, elements
 constexpr int kCtThreads = 256;
 
-// ---------------------------------------------------------------- 8-element loads
-template <typename IT>
-struct Load8;
-
-template <>
-struct Load8<bf16_t> {
-  static __device__ __forceinline__ void run(const bf16_t *p, float (&f)[8]) {
-    const u32x4 v = ld_stream<u32x4>(p);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      f[2 * k] = __uint_as_float(v[k] << 16);
-      f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
-    }
-  }
-};
-
-template <>
-struct Load8<f16_t> {
-  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-  static __device__ __forceinline__ void run(const f16_t *p, float (&f)[8]) {
-    const h8 v = ld_stream<h8>(p);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(v[k]);
-  }
-};
-
-template <>
-struct Load8<float> {
-  static __device__ __forceinline__ void run(const float *p, float (&f)[8]) {
-    const f32x4 a = ld_stream<f32x4>(p);
-    const f32x4 b = ld_stream<f32x4>(p + 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      f[k] = a[k];
-      f[4 + k] = b[k];
-    }
-  }
-};
-
 // ---------------------------------------------------------------- aligned 128x128 tile kernel
 // Requires rows % 128 == 0, cols % 128 == 0, 16-byte aligned base pointers.
 template <typename IT, Fp8 F>

@@ -201,6 +201,54 @@ void check_scale_shapes(const Tensor &t, const char *name);
 void check_input(const Tensor &t, const char *name, bool check_scale_shapes_too = true);
 void check_output(const Tensor &t, const char *name, bool allow_empty = false);
 
+// ---------------------------------------------------------------- grouped tensor descriptor
+// ref common/common.h:452-600.  All payload buffers are flat 1-D; member i is the
+// [first_i, last_i] matrix at element offset tensor_offsets[i] (or i * M * N when uniform).
+struct GroupedTensor {
+  Buf data, columnwise_data, scale_inv, columnwise_scale_inv, amax, columnwise_amax, scale;
+  Buf first_dims, last_dims, tensor_offsets;  // device int64 arrays, absent when uniform
+  NVTEScalingMode scaling_mode = NVTE_DELAYED_TENSOR_SCALING;
+  size_t num_tensors = 0;
+  NVTEShape logical_shape{{0}, 1};
+  bool with_gemm_swizzled_scales = false;
+  bool live = false;
+
+  bool has_data() const { return data.present(); }
+  bool has_columnwise_data() const { return columnwise_data.present(); }
+  bool all_same_first_dim() const { return !first_dims.present(); }
+  bool all_same_last_dim() const { return !last_dims.present(); }
+  bool all_same_shape() const { return all_same_first_dim() && all_same_last_dim(); }
+  bool varying_both_dims() const { return !all_same_first_dim() && !all_same_last_dim(); }
+  DType dtype() const { return (!has_data() && has_columnwise_data()) ? columnwise_data.dtype : data.dtype; }
+  size_t common_first_dim() const;  // throws when the first dim varies
+  size_t common_last_dim() const;   // throws when the last dim varies
+};
+
+GroupedTensor *lookup_grouped(NVTEGroupedTensor h);          // nullptr for null / dead handles
+GroupedTensor *lookup_grouped_checked(NVTEGroupedTensor h);  // throws instead
+// ref common/transformer_engine.cpp:261-395
+void check_grouped_input(const GroupedTensor &t, const char *name);
+void check_grouped_output(const GroupedTensor &t, const char *name, bool allow_empty = false);
+
+// Member shapes as the kernels take them: uniform values from the host side of the descriptor,
+// per-member arrays as device pointers (null = uniform).
+struct GroupShapes {
+  const int64_t *first_dims = nullptr;
+  const int64_t *last_dims = nullptr;
+  const int64_t *offsets = nullptr;  // num_tensors + 1 entries, or null
+  int64_t uniform_first = 0;
+  int64_t uniform_last = 0;
+  unsigned num_tensors = 0;
+};
+GroupShapes group_shapes_of(const GroupedTensor &t);
+
+struct GroupedMatmulConfig {
+  int64_t avg_m = 0, avg_n = 0, avg_k = 0;
+  bool has_avg_m = false, has_avg_n = false, has_avg_k = false;
+  int sm_count = 0;
+  bool use_split_accumulator = false;
+};
+
 // ---------------------------------------------------------------- configs
 struct QuantConfig {
   bool force_pow_2_scales = false;

@@ -214,8 +214,12 @@ __device__ __forceinline__ void transpose4x4_bytes(uint32_t &r0, uint32_t &r1, u
 // chunks, chunk rg at slot rg ^ (c/8): conflict-free for the 16-lane b64 groups), and after one
 // barrier written out 16 B per thread per pass: one wave instruction = eight full 128-B lines
 // of out_t, whose row c starts at out_t + c * ld.  `q` is clobbered.
+// GUARD: only 16-row chunks k < valid_chunks of transposed rows c < valid_cols are written
+// (partial tiles of the grouped quantize; rows per member are a multiple of 16 there).
+template <bool GUARD = false>
 __device__ __forceinline__ void store_tile_transposed(uint8_t *tile_t, uint32_t (&q)[8][2], unsigned t,
-                                                      uint8_t *out_t, size_t ld) {
+                                                      uint8_t *out_t, size_t ld, unsigned valid_chunks = 8,
+                                                      unsigned valid_cols = 128) {
   const unsigned cg = t & 15u, rg = t >> 4;
   transpose4x4_bytes(q[0][0], q[1][0], q[2][0], q[3][0]);  // rows 0-3, cols 0-3
   transpose4x4_bytes(q[0][1], q[1][1], q[2][1], q[3][1]);  // rows 0-3, cols 4-7
@@ -242,10 +246,66 @@ __device__ __forceinline__ void store_tile_transposed(uint8_t *tile_t, uint32_t 
       u32x4 w = {v[2], v[3], v[0], v[1]};
       v = w;
     }
+    if constexpr (GUARD) {
+      if (k >= valid_chunks || c >= valid_cols) continue;
+    }
     *reinterpret_cast<u32x4 *>(out_t + c * ld + k * 16) = v;
   }
 }
 
 __device__ __forceinline__ bool noop_set(const float *noop) { return noop != nullptr && noop[0] == 1.0f; }
+
+// ------------------------------------------------------------------ 8-element streaming loads -> fp32
+template <typename IT>
+struct Load8;
+
+template <>
+struct Load8<bf16_t> {
+  static __device__ __forceinline__ void run(const bf16_t *p, float (&f)[8]) {
+    const u32x4 v = ld_stream<u32x4>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = __uint_as_float(v[k] << 16);
+      f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
+    }
+  }
+};
+
+template <>
+struct Load8<f16_t> {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ void run(const f16_t *p, float (&f)[8]) {
+    const h8 v = ld_stream<h8>(p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(v[k]);
+  }
+};
+
+template <>
+struct Load8<float> {
+  static __device__ __forceinline__ void run(const float *p, float (&f)[8]) {
+    const f32x4 a = ld_stream<f32x4>(p);
+    const f32x4 b = ld_stream<f32x4>(p + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] = a[k];
+      f[4 + k] = b[k];
+    }
+  }
+};
+
+
+// ------------------------------------------------------------------ scale from amax
+// ref common/recipe/recipe_common.cuh:14-49
+__device__ __forceinline__ float scale_from_amax(float amax, float max_fp8, bool pow2, float eps,
+                                                 float value_for_inf) {
+  if (amax < eps) amax = eps;  // false for NaN
+  if (__builtin_isinf(amax) || amax == 0.f || amax != amax) return 1.f;
+  float scale = max_fp8 / amax;  // IEEE-rounded division (no fast-math in this library)
+  if (__builtin_isinf(scale)) scale = value_for_inf;
+  if (pow2) scale = __uint_as_float(__float_as_uint(scale) & 0xFF800000u);
+  return scale;
+}
+
 
 }  // namespace te

@@ -78,6 +78,23 @@ struct GemmArgs {
   const float *d_scale;   // FP8 output: scale (device, null = 1) ...
   float *d_amax;          // ... and amax of the unscaled output (device, may be null)
   float *dbias_acc;       // DGELU_BGRAD: fp32 [m] column sums of D (atomics), or null
+  // grouped launch (kernel variant GROUPED = true only): per-member problems + tile prefix,
+  // both written on the device by grouped_setup_kernel
+  const struct GroupDesc *groups;
+  const unsigned *group_tile_start;  // [num_groups + 1]
+  unsigned num_groups;
+};
+
+// One member GEMM of a grouped launch.
+struct GroupDesc {
+  const uint8_t *P;  // [n, k]
+  const uint8_t *Q;  // [m, k]
+  void *D;           // [n, m]
+  const void *C;     // accumulation input (== D, another buffer, or null)
+  float mult;        // alpha * scale_inv(P) * scale_inv(Q); NaN marks an inconsistent member
+  float beta;
+  unsigned n, m, k;
+  unsigned tiles_j;
 };
 
 constexpr int kEpiNone = 0;
@@ -161,8 +178,12 @@ __device__ __forceinline__ void store_any(void *p, size_t idx, int dtype, float 
 //  * EPI = true is the same kernel with the extended epilogue (GELU / dGELU with the aux matrix,
 //    bias-gradient column sums, FP8 output with amax) - element-wise, off the Linear hot path;
 //    the plain instantiation is untouched by it.
-template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, bool EPI>
+//  * GROUPED = true walks the tiles of MANY member GEMMs (one persistent launch for all experts):
+//    member shapes and pointers come from device memory (GroupDesc), every member runs at least
+//    two K tiles (the K tail is zero-filled anyway) so that the cross-tile pipeline is uniform.
+template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, bool EPI, bool GROUPED = false>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
+  static_assert(!(GROUPED && (MX || EPI)), "the grouped variant is per-tensor-scaled FP8 without epilogues");
   // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
   constexpr int kScaleBase = 2 * kStageBytes;
   constexpr int kEpiBase = kScaleBase + (MX ? 2 * kScaleSlotBytes : 0);
@@ -176,6 +197,12 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   const unsigned wi = wave >> 2, wj = wave & 3u;
   const unsigned tiles_i = (a.n + BM - 1) / BM;
   const unsigned nk = (a.k + BK - 1) / BK;
+  unsigned total_tiles = a.ntiles;
+  unsigned grp = 0;  // GROUPED: member that holds the tile located last (tiles only move forward)
+  if constexpr (GROUPED) {
+    total_tiles = a.group_tile_start[a.num_groups];
+    if (blockIdx.x >= total_tiles) return;  // whole workgroup, before any barrier
+  }
 
   // MX: the scale buffer this wave stages (P's for waves 0-3, Q's for waves 4-7)
   const uint8_t *e_base = wave < 4 ? a.eP : a.eQ;
@@ -192,10 +219,50 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     unsigned pbytes, qbytes;     // bytes the tile's descriptors may touch (0 = everything reads 0)
     unsigned i0, j0;
     unsigned ss;                 // MX: scalar part of this wave's scale source address (K tile 0)
+    // GROUPED only: the member's own problem
+    unsigned n, m, k;
+    float mult, beta;
+    char *D;
+    const char *C;
   };
   auto make_tile = [&](unsigned tile, bool valid) {
     TileCtx t;
     unsigned ti, tj;
+    if constexpr (GROUPED) {
+      if (!valid) tile = 0;
+      {
+        // same XCD-aware remap as tile_of: the workgroups of one XCD (id % 8) walk a contiguous run
+        // of the global tile list, so an XCD's L2 holds few P / Q panels at a time.  A workgroup's
+        // successive tiles keep their XCD, hence still move forward through the members.
+        const unsigned q8 = total_tiles / 8, r8 = total_tiles % 8, xcd = tile % 8, loc = tile / 8;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+      }
+      while (grp + 1 < a.num_groups && tile >= a.group_tile_start[grp + 1]) ++grp;
+      if (!valid) grp = 0;
+      const GroupDesc &d = a.groups[grp];
+      const unsigned local = tile - a.group_tile_start[grp];
+      // tiles in groups of 8 tile rows, column by column inside a group (panel reuse in L2)
+      const unsigned m_tiles_i = (d.n + BM - 1) / BM;
+      const unsigned per_group = 8 * d.tiles_j;
+      const unsigned first_i = (local / per_group) * 8;
+      const unsigned gsz = min(m_tiles_i - first_i, 8u);
+      const unsigned in_g = local % per_group;
+      ti = first_i + in_g % gsz;
+      tj = in_g / gsz;
+      t.i0 = ti * BM;
+      t.j0 = tj * BN;
+      t.n = d.n; t.m = d.m; t.k = d.k;
+      t.mult = d.mult; t.beta = d.C ? d.beta : 0.f;
+      t.D = static_cast<char *>(d.D);
+      t.C = static_cast<const char *>(d.C ? d.C : d.D);
+      const unsigned rows_p = valid ? min(d.n - t.i0, static_cast<unsigned>(BM)) : 0u;
+      const unsigned rows_q = valid ? min(d.m - t.j0, static_cast<unsigned>(BN)) : 0u;
+      t.pbase = const_cast<uint8_t *>(d.P) + static_cast<size_t>(t.i0) * d.k;
+      t.qbase = const_cast<uint8_t *>(d.Q) + static_cast<size_t>(t.j0) * d.k;
+      t.pbytes = rows_p * d.k;
+      t.qbytes = rows_q * d.k;
+      return t;
+    }
     tile_of(valid ? tile : 0u, a.ntiles, tiles_i, a.tiles_j, ti, tj);
     t.i0 = ti * BM;
     t.j0 = tj * BN;
@@ -229,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // two glds instructions (rows q*8.. of this wave's 32-row share of P and of Q)
   auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
     uint8_t *base = lds + slot * kStageBytes;
-    const unsigned soff = (wave * 4 + q) * 8 * a.k + k0;
+    const unsigned soff = (wave * 4 + q) * 8 * (GROUPED ? t.k : a.k) + k0;
     lds_u8 *dst_p = (lds_u8 *)(base + (wave * 4 + q) * 1024);
     lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
@@ -237,13 +304,18 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, 0);
   };
-  auto stage_voff = [&](unsigned k0, unsigned(&voff)[2]) {
+  auto stage_voff = [&](const TileCtx &t, unsigned k0, unsigned(&voff)[2]) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) voff[q] = (k0 + st_chunk_k[q] < a.k) ? st_voff[q] : kOOB;
+    for (int q = 0; q < 2; ++q) {
+      if constexpr (GROUPED)
+        voff[q] = (k0 + st_chunk_k[q] < t.k) ? (lane >> 3) * t.k + st_chunk_k[q] : kOOB;
+      else
+        voff[q] = (k0 + st_chunk_k[q] < a.k) ? st_voff[q] : kOOB;
+    }
   };
   auto stage = [&](const TileCtx &t, unsigned slot, unsigned k0) {
     unsigned voff[2];
-    stage_voff(k0, voff);
+    stage_voff(t, k0, voff);
 #pragma unroll
     for (int q = 0; q < 4; ++q) stage_rows(t, slot, k0, q, voff);
   };
@@ -397,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     rdP(cur, 1, 3, p[3]);
     mm(I1{}, I0{}, I0{}, p[0], q[1][0]);
     unsigned voff[2];
-    stage_voff(st_k0, voff);
+    stage_voff(st, st_k0, voff);
     mm(I1{}, I0{}, I1{}, p[0], q[1][1]);
     // Every wave has now pulled all of this K tile out of slot `cur` (last read: two MFMAs ago);
     // the next K tile (issued most of a tile ago) has landed.  After the barrier the slot is
@@ -435,10 +507,10 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   float *stg = reinterpret_cast<float *>(lds + kEpiBase) + wave * (kEpiRows * 64);
   const unsigned e_row = lane >> 4;          // 0..3
   const unsigned e_col = (lane & 15u) * 4u;  // 0..60
-  float mult = a.alpha;
-  if constexpr (!MX) {
-    if (a.sP) mult *= *a.sP;
-    if (a.sQ) mult *= *a.sQ;
+  float mult0 = a.alpha;
+  if constexpr (!MX && !GROUPED) {
+    if (a.sP) mult0 *= *a.sP;
+    if (a.sQ) mult0 *= *a.sQ;
   }
   // FULL = the tile lies inside D and rows are vector-aligned: no per-element guards (and no
   // divergent control flow, which would make the compiler drain every store before the next
@@ -449,17 +521,22 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     constexpr bool FULL = decltype(full_tag)::value;
     using VecT = std::conditional_t<sizeof(OT) == 4, u32x4, u32x2>;
     const unsigned jbase = t.j0 + wj * 64 + e_col;
+    // the problem this tile belongs to: the launch's (folded to kernel arguments) or its member's
+    const unsigned e_n = GROUPED ? t.n : a.n, e_m = GROUPED ? t.m : a.m, e_ldd = GROUPED ? t.m : a.ldd;
+    const float mult = GROUPED ? t.mult : mult0, e_beta = GROUPED ? t.beta : a.beta;
+    // where the accumulation input sits relative to the output (0 unless a grouped C != D)
+    const ptrdiff_t c_delta = GROUPED ? (t.C - t.D) : 0;
     float bias[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
+    if (!GROUPED && a.bias) {
 #pragma unroll
       for (int x = 0; x < 4; ++x)
-        if (FULL || jbase + x < a.m) bias[x] = load_any(a.bias, jbase + x, a.bias_dtype);
+        if (FULL || jbase + x < e_m) bias[x] = load_any(a.bias, jbase + x, a.bias_dtype);
     }
     // first (unconditional) use of the bias registers: the wait for their loads happens here, once
     asm volatile("" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]));
     // wave-uniform 64-bit base of this wave's 128 x 64 block + a 32-bit lane offset
-    char *wave_base = reinterpret_cast<char *>(dptr + static_cast<size_t>(t.i0 + wi * 128) * a.ldd + t.j0 + wj * 64);
-    const unsigned lane_off = (e_row * a.ldd + e_col) * static_cast<unsigned>(sizeof(OT));
+    char *wave_base = reinterpret_cast<char *>(dptr + static_cast<size_t>(t.i0 + wi * 128) * e_ldd + t.j0 + wj * 64);
+    const unsigned lane_off = (e_row * e_ldd + e_col) * static_cast<unsigned>(sizeof(OT));
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -477,26 +554,27 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
           const unsigned l = ps * 4 + e_row;
           const f32x4 v4 = *reinterpret_cast<const f32x4 *>(stg + l * 64 + (e_col ^ (32u * (ps & 1))));
           const unsigned li = mi * 32 + part * kEpiRows + l;  // row inside this wave's 128
-          OT *dst = reinterpret_cast<OT *>(wave_base + static_cast<size_t>(mi * 32 + part * kEpiRows + ps * 4) * a.ldd * sizeof(OT) + lane_off);
+          OT *dst = reinterpret_cast<OT *>(wave_base + static_cast<size_t>(mi * 32 + part * kEpiRows + ps * 4) * e_ldd * sizeof(OT) + lane_off);
+          const OT *csrc = reinterpret_cast<const OT *>(reinterpret_cast<const char *>(dst) + c_delta);
           float v[4] = {v4[0] * mult, v4[1] * mult, v4[2] * mult, v4[3] * mult};
           if constexpr (FULL) {
             if constexpr (WITH_C) {
               OT old[4];
-              *reinterpret_cast<VecT *>(old) = *reinterpret_cast<const VecT *>(dst);
+              *reinterpret_cast<VecT *>(old) = *reinterpret_cast<const VecT *>(csrc);
 #pragma unroll
-              for (int x = 0; x < 4; ++x) v[x] += a.beta * widen(old[x]);
+              for (int x = 0; x < 4; ++x) v[x] += e_beta * widen(old[x]);
             }
             OT o[4];
 #pragma unroll
             for (int x = 0; x < 4; ++x) narrow(v[x] + bias[x], o[x]);
             *reinterpret_cast<VecT *>(dst) = *reinterpret_cast<const VecT *>(o);
           } else {
-            if (t.i0 + wi * 128 + li >= a.n) continue;
+            if (t.i0 + wi * 128 + li >= e_n) continue;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-              if (jbase + x >= a.m) continue;
+              if (jbase + x >= e_m) continue;
               float y = v[x];
-              if constexpr (WITH_C) y += a.beta * widen(dst[x]);
+              if constexpr (WITH_C) y += e_beta * widen(csrc[x]);
               narrow(y + bias[x], dst[x]);
             }
           }
@@ -507,9 +585,11 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   };
   auto epilogue_typed = [&](const TileCtx &t, auto *dptr) {
     using OT = std::remove_pointer_t<decltype(dptr)>;
-    const bool full = t.i0 + BM <= a.n && t.j0 + BN <= a.m && a.ldd % 4 == 0 &&
-                      reinterpret_cast<uintptr_t>(dptr) % (4 * sizeof(OT)) == 0;
-    const bool with_c = a.beta != 0.f;
+    const unsigned e_n = GROUPED ? t.n : a.n, e_m = GROUPED ? t.m : a.m, e_ldd = GROUPED ? t.m : a.ldd;
+    bool full = t.i0 + BM <= e_n && t.j0 + BN <= e_m && e_ldd % 4 == 0 &&
+                reinterpret_cast<uintptr_t>(dptr) % (4 * sizeof(OT)) == 0;
+    if constexpr (GROUPED) full = full && reinterpret_cast<uintptr_t>(t.C) % (4 * sizeof(OT)) == 0;
+    const bool with_c = (GROUPED ? t.beta : a.beta) != 0.f;
     if (full) {
       with_c ? epilogue_as(t, dptr, std::true_type{}, std::true_type{}) : epilogue_as(t, dptr, std::false_type{}, std::true_type{});
     } else {
@@ -559,7 +639,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
             const unsigned gj = jbase + x;
             if (gj >= a.m) continue;
             const size_t idx = static_cast<size_t>(gi) * a.ldd + gj;
-            float y = v4[x] * mult;
+            float y = v4[x] * mult0;
             if (a.beta != 0.f) y += a.beta * load_any(a.D, idx, a.d_dtype);
             y += bias[x];
             if (a.epi == kEpiGeluAux) {
@@ -599,10 +679,12 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       epilogue_ext(t);
       return;
     }
+    void *dbase = a.D;
+    if constexpr (GROUPED) dbase = t.D;
     switch (a.d_dtype) {
-      case kNVTEFloat32: epilogue_typed(t, static_cast<float *>(a.D)); break;
-      case kNVTEBFloat16: epilogue_typed(t, static_cast<bf16_t *>(a.D)); break;
-      default: epilogue_typed(t, static_cast<f16_t *>(a.D)); break;
+      case kNVTEFloat32: epilogue_typed(t, static_cast<float *>(dbase)); break;
+      case kNVTEBFloat16: epilogue_typed(t, static_cast<bf16_t *>(dbase)); break;
+      default: epilogue_typed(t, static_cast<f16_t *>(dbase)); break;
     }
   };
 
@@ -637,11 +719,13 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   unsigned g = 0;
   while (true) {
     const unsigned next = tile + gridDim.x;
-    const bool has_next = next < a.ntiles;
+    const bool has_next = next < total_tiles;
     const TileCtx next_t = make_tile(next, has_next);
-    for (unsigned kt = 0; kt + 2 < nk; ++kt, ++g) k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, std::true_type{});
-    if (nk >= 2) {
-      k_tile(g, next_t, 0, 0, nk - 1, std::true_type{});
+    // K tiles of THIS output tile: the launch's, or the member's (never fewer than two)
+    const unsigned nk_t = GROUPED ? max((cur_t.k + BK - 1) / BK, 2u) : nk;
+    for (unsigned kt = 0; kt + 2 < nk_t; ++kt, ++g) k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, std::true_type{});
+    if (nk_t >= 2) {
+      k_tile(g, next_t, 0, 0, nk_t - 1, std::true_type{});
       ++g;
     }
     // the last K tile leaves the fragment registers dead, so the epilogue has room to work in
@@ -658,12 +742,12 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <bool MX, bool EPI>
+template <bool MX, bool EPI, bool GROUPED = false>
 void launch_by_format(int fa, int fb, const GemmArgs &args, hipStream_t stream) {
   const dim3 grid(args.grid), block(kThreads);
 #define TE_GEMM_CASE(A_, B_)                                                                       \
   if (fa == A_ && fb == B_) {                                                                      \
-    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX, EPI>), grid, block, 0, stream, args);         \
+    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX, EPI, GROUPED>), grid, block, 0, stream, args); \
     NVTE_CHECK_HIP(hipGetLastError());                                                             \
     return;                                                                                        \
   }
@@ -958,6 +1042,288 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Grouped GEMM (ref common/gemm/cublaslt_grouped_gemm.cu): D[i] = alpha[i] op(A[i]) op(B[i]) +
+// beta[i] C[i] for all members in ONE persistent launch.  A device-side setup kernel turns the
+// grouped tensors' metadata (first_dims / last_dims / tensor_offsets, all device arrays) into
+// per-member GroupDesc records + a tile prefix in workspace_setup; the main kernel walks the
+// global tile list.  No host read of any member shape: HIP-graph safe.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kMaxListed = 64;  // discrete A / C / D lists travel in the kernel arguments
+
+struct GroupedOperandMeta {
+  const uint8_t *base = nullptr;     // payload of the storage picked (null: discrete list)
+  const float *scale_inv = nullptr;  // one entry per member
+  GroupShapes shapes;
+};
+struct GroupedOutMeta {
+  char *base = nullptr;  // null: discrete list (or absent, for C)
+  GroupShapes shapes;
+};
+struct ListedInputs {
+  const uint8_t *ptr[kMaxListed];
+  const float *scale_inv[kMaxListed];
+  unsigned first[kMaxListed], last[kMaxListed];  // LOGICAL dims of the member
+};
+struct ListedOutputs {
+  char *d[kMaxListed];
+  const char *c[kMaxListed];
+  unsigned first[kMaxListed], last[kMaxListed];
+};
+
+__device__ __forceinline__ void member_dims(const GroupShapes &g, unsigned i, int64_t &first, int64_t &last,
+                                            int64_t &off) {
+  first = g.first_dims ? g.first_dims[i] : g.uniform_first;
+  last = g.last_dims ? g.last_dims[i] : g.uniform_last;
+  off = g.offsets ? g.offsets[i] : static_cast<int64_t>(i) * g.uniform_first * g.uniform_last;
+}
+
+// One wave: lane l builds the records of members [l * per, (l + 1) * per) and the tile prefix.
+__global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, unsigned *tile_start,
+                                                           const GroupedOperandMeta A, const GroupedOperandMeta B,
+                                                           const GroupedOutMeta C, const GroupedOutMeta D,
+                                                           const ListedInputs la, const ListedOutputs lo,
+                                                           const float *alpha, int alpha_n, const float *beta,
+                                                           int beta_n, unsigned G, int transa, int transb,
+                                                           unsigned d_elem_bytes, int has_c) {
+  const unsigned lane = threadIdx.x;
+  const unsigned per = (G + 63) / 64, lo_i = lane * per, hi_i = min(lo_i + per, G);
+  unsigned local = 0;
+  for (unsigned i = lo_i; i < hi_i; ++i) {
+    int64_t a_first, a_last, a_off = 0, b_first, b_last, b_off, d_first, d_last, d_off = 0;
+    const uint8_t *q_ptr;
+    const float *q_scale;
+    if (A.base) {
+      member_dims(A.shapes, i, a_first, a_last, a_off);
+      q_ptr = A.base + a_off;
+      q_scale = A.scale_inv + i;
+    } else {
+      a_first = la.first[i];
+      a_last = la.last[i];
+      q_ptr = la.ptr[i];
+      q_scale = la.scale_inv[i];
+    }
+    member_dims(B.shapes, i, b_first, b_last, b_off);
+    char *d_ptr;
+    const char *c_ptr = nullptr;
+    if (D.base) {
+      member_dims(D.shapes, i, d_first, d_last, d_off);
+      d_ptr = D.base + d_off * d_elem_bytes;
+      if (has_c) {
+        int64_t c_first, c_last, c_off;
+        member_dims(C.base ? C.shapes : D.shapes, i, c_first, c_last, c_off);
+        c_ptr = (C.base ? C.base : D.base) + c_off * d_elem_bytes;
+      }
+    } else {
+      d_first = lo.first[i];
+      d_last = lo.last[i];
+      d_ptr = lo.d[i];
+      if (has_c) c_ptr = lo.c[i];
+    }
+    const int64_t m = transa ? a_first : a_last, ka = transa ? a_last : a_first;
+    const int64_t n = transb ? b_last : b_first, kb = transb ? b_first : b_last;
+    // the stores follow D's own shape; anything inconsistent (or a K the 16-byte loads cannot take)
+    // turns the member's output into NaN instead of reading out of bounds
+    const bool ok = d_first == n && d_last == m && ka == kb && ka % 16 == 0 && ka <= (1 << 23);
+    GroupDesc d;
+    d.P = B.base + b_off;
+    d.Q = q_ptr;
+    d.D = d_ptr;
+    d.C = c_ptr;
+    d.n = static_cast<unsigned>(d_first);
+    d.m = static_cast<unsigned>(d_last);
+    d.k = ok ? static_cast<unsigned>(ka) : 0u;
+    d.mult = ok ? alpha[alpha_n > 1 ? i : 0] * B.scale_inv[i] * *q_scale : __builtin_nanf("");
+    d.beta = has_c ? beta[beta_n > 1 ? i : 0] : 0.f;
+    d.tiles_j = (d.m + BN - 1) / BN;
+    descs[i] = d;
+    local += ((d.n + BM - 1) / BM) * d.tiles_j;
+  }
+  unsigned incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<unsigned>(off)) incl += up;
+  }
+  unsigned run = incl - local;
+  for (unsigned i = lo_i; i < hi_i; ++i) {
+    tile_start[i] = run;
+    run += ((descs[i].n + BM - 1) / BM) * descs[i].tiles_j;
+  }
+  if (lane == 63) tile_start[G] = incl;
+}
+
+size_t grouped_setup_bytes(size_t G) { return round_up(G * sizeof(GroupDesc), 256) + (G + 1) * sizeof(unsigned) + 256; }
+
+// Pick the K-contiguous storage of an FP8 grouped operand ("TN everywhere", like the ungrouped path
+// and ref cublaslt_grouped_gemm.cu:551-565): rowwise when the contraction runs along the member's last
+// dim, else the per-member transposed ("columnwise") copy.
+GroupedOperandMeta pick_grouped_operand(const GroupedTensor &t, bool k_is_last, const char *name, DType &dtype) {
+  NVTE_CHECK(is_tensor_scaling(t.scaling_mode),
+             "Grouped GEMM: only FP8 per-tensor scaling is implemented in this library, ", name, " has ",
+             scaling_mode_name(t.scaling_mode));
+  GroupedOperandMeta m;
+  if (k_is_last) {
+    NVTE_CHECK(t.has_data(), "Grouped GEMM: ", name, " is missing row-wise data");
+    m.base = static_cast<const uint8_t *>(t.data.ptr);
+    m.scale_inv = static_cast<const float *>(t.scale_inv.ptr);
+    dtype = t.data.dtype;
+  } else {
+    NVTE_CHECK(t.has_columnwise_data(), "Grouped GEMM: ", name, " is missing column-wise data needed for TN layout");
+    m.base = static_cast<const uint8_t *>(t.columnwise_data.ptr);
+    m.scale_inv = static_cast<const float *>(t.columnwise_scale_inv.ptr);
+    dtype = t.columnwise_data.dtype;
+  }
+  NVTE_CHECK(is_fp8(dtype), "Grouped GEMM: this library implements FP8 operands only, ", name, " is ",
+             dtype_name(dtype));
+  NVTE_CHECK(m.scale_inv != nullptr, "Grouped GEMM: FP8 input ", name, " requires inverse of scale!");
+  NVTE_CHECK((reinterpret_cast<uintptr_t>(m.base) & 15u) == 0, "Grouped GEMM: ", name, " must be 16-byte aligned");
+  m.shapes = group_shapes_of(t);
+  return m;
+}
+
+struct GroupedCall {
+  const GroupedTensor *A = nullptr;  // or a_list
+  const NVTETensor *a_list = nullptr;
+  const GroupedTensor *B = nullptr;
+  const GroupedTensor *C = nullptr;  // or c_list, or neither
+  GroupedTensor *D = nullptr;        // or d_list
+  const NVTETensor *c_list = nullptr;
+  NVTETensor *d_list = nullptr;
+  size_t num_c = 0;
+};
+
+void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool transa, bool transb,
+                       const NVTETensor alpha_, const NVTETensor beta_, NVTETensor ws_setup_,
+                       NVTEGroupedMatmulConfig config, hipStream_t stream) {
+  NVTE_CHECK(G >= 1, "Grouped GEMM: number of tensors must be at least 1");
+  NVTE_CHECK(G <= 1024, "Grouped GEMM: at most 1024 member tensors are supported, got ", G);
+  const Tensor &alpha = *lookup_checked(alpha_);
+  const Tensor &beta = *lookup_checked(beta_);
+  NVTE_CHECK(alpha.data.dtype == kNVTEFloat32 && beta.data.dtype == kNVTEFloat32 && alpha.data.ptr && beta.data.ptr,
+             "Grouped GEMM: alpha and beta must be FP32 device tensors");
+  NVTE_CHECK(alpha.data.numel() == G || alpha.data.numel() == 1, "Grouped GEMM: alpha must have ", G,
+             " (or 1) elements, got ", alpha.data.numel());
+  NVTE_CHECK(beta.data.numel() == G || beta.data.numel() == 1, "Grouped GEMM: beta must have ", G,
+             " (or 1) elements, got ", beta.data.numel());
+
+  DType a_dtype = kNVTEByte, b_dtype = kNVTEByte;
+  GroupedOperandMeta A, B;
+  ListedInputs la;
+  ListedOutputs lo;
+  std::memset(&la, 0, sizeof(la));
+  std::memset(&lo, 0, sizeof(lo));
+  NVTE_CHECK(call.B->num_tensors == G, "Grouped GEMM: B must have num_tensors = ", G);
+  check_grouped_input(*call.B, "B");
+  B = pick_grouped_operand(*call.B, !transb, "B", b_dtype);
+  if (call.A != nullptr) {
+    NVTE_CHECK(call.A->num_tensors == G, "Grouped GEMM: A must have num_tensors = ", G);
+    check_grouped_input(*call.A, "A");
+    A = pick_grouped_operand(*call.A, transa, "A", a_dtype);
+  } else {
+    NVTE_CHECK(G <= static_cast<size_t>(kMaxListed), "Grouped GEMM: A_list supports at most ", kMaxListed,
+               " tensors, got ", G);
+    for (size_t i = 0; i < G; ++i) {
+      const Tensor &t = *lookup_checked(call.a_list[i]);
+      NVTE_CHECK(is_tensor_scaling(t.scaling_mode), "Grouped GEMM: A_list tensor ", i,
+                 " must use FP8 per-tensor scaling");
+      const Buf &payload = transa ? t.data : t.columnwise_data;
+      const Buf &sinv = transa ? t.scale_inv : t.columnwise_scale_inv;
+      NVTE_CHECK(payload.ptr != nullptr, "Grouped GEMM: A_list tensor ", i, " is missing ",
+                 transa ? "row-wise" : "column-wise", " data");
+      NVTE_CHECK(is_fp8(payload.dtype), "Grouped GEMM: A_list tensor ", i, " must be FP8");
+      NVTE_CHECK(sinv.ptr != nullptr, "Grouped GEMM: A_list tensor ", i, " is missing scale_inv");
+      NVTE_CHECK((reinterpret_cast<uintptr_t>(payload.ptr) & 15u) == 0, "Grouped GEMM: A_list tensor ", i,
+                 " must be 16-byte aligned");
+      if (i == 0) a_dtype = payload.dtype;
+      NVTE_CHECK(payload.dtype == a_dtype, "Grouped GEMM: A_list tensors must share one dtype");
+      const auto dims = t.flat2d();  // logical [first, last]
+      NVTE_CHECK(dims[0] < (1ull << 31) && dims[1] < (1ull << 31), "Grouped GEMM: A_list tensor ", i, " too large");
+      la.ptr[i] = static_cast<const uint8_t *>(payload.ptr);
+      la.scale_inv[i] = static_cast<const float *>(sinv.ptr);
+      la.first[i] = static_cast<unsigned>(dims[0]);
+      la.last[i] = static_cast<unsigned>(dims[1]);
+    }
+  }
+
+  GroupedOutMeta C, D;
+  DType d_dtype;
+  int has_c = 0;
+  if (call.D != nullptr) {
+    NVTE_CHECK(call.D->num_tensors == G, "Grouped GEMM: D must have num_tensors = ", G);
+    check_grouped_output(*call.D, "D", false);
+    NVTE_CHECK(call.D->has_data(), "Grouped GEMM: D is missing row-wise data");
+    d_dtype = call.D->data.dtype;
+    D.base = static_cast<char *>(call.D->data.ptr);
+    D.shapes = group_shapes_of(*call.D);
+    if (call.C != nullptr) {
+      NVTE_CHECK(call.C->num_tensors == G, "Grouped GEMM: C must have num_tensors = ", G);
+      NVTE_CHECK(call.C->has_data(), "Grouped GEMM: C is missing row-wise data");
+      NVTE_CHECK(call.C->data.dtype == d_dtype, "Grouped GEMM: C and D must have the same dtype");
+      C.base = static_cast<char *>(call.C->data.ptr);
+      C.shapes = group_shapes_of(*call.C);
+      has_c = 1;
+    }
+  } else {
+    NVTE_CHECK(G <= static_cast<size_t>(kMaxListed), "Grouped GEMM: D_list supports at most ", kMaxListed,
+               " tensors, got ", G);
+    has_c = call.num_c > 0;
+    d_dtype = lookup_checked(call.d_list[0])->data.dtype;
+    for (size_t i = 0; i < G; ++i) {
+      const Tensor &t = *lookup_checked(call.d_list[i]);
+      NVTE_CHECK(t.has_data(), "Grouped GEMM: D_list tensor ", i, " has no data");
+      NVTE_CHECK(t.data.dtype == d_dtype, "Grouped GEMM: D_list tensor ", i, " has a different dtype");
+      NVTE_CHECK(t.data.shape.ndim == 2, "Grouped GEMM: D_list tensor ", i, " must be 2D.");
+      lo.d[i] = static_cast<char *>(t.data.ptr);
+      lo.first[i] = static_cast<unsigned>(t.data.shape.data[0]);
+      lo.last[i] = static_cast<unsigned>(t.data.shape.data[1]);
+      if (has_c) {
+        const Tensor &c = *lookup_checked(call.c_list[i]);
+        NVTE_CHECK(c.has_data(), "Grouped GEMM: C_list tensor ", i, " has no data");
+        NVTE_CHECK(c.data.dtype == d_dtype, "Grouped GEMM: C_list tensor ", i, " has a different dtype");
+        NVTE_CHECK(c.data.numel() == t.data.numel(), "Grouped GEMM: C_list tensor ", i, " has a different size");
+        lo.c[i] = static_cast<const char *>(c.data.ptr);
+      }
+    }
+  }
+  NVTE_CHECK(is_high_precision(d_dtype), "Grouped GEMM: D must be BF16, FP16, or FP32.");
+
+  Tensor &ws = *lookup_checked(ws_setup_);
+  const size_t ws_bytes = ws.data.numel() * dtype_bits(ws.data.dtype) / 8;
+  NVTE_CHECK(ws.data.ptr != nullptr && ws_bytes >= grouped_setup_bytes(G), "Grouped GEMM: Insufficient setup workspace (",
+             ws_bytes, " bytes, need ", grouped_setup_bytes(G), ": nvte_get_grouped_gemm_setup_workspace_size)");
+  const uintptr_t ws_al = (reinterpret_cast<uintptr_t>(ws.data.ptr) + 255) & ~static_cast<uintptr_t>(255);
+  GroupDesc *descs = reinterpret_cast<GroupDesc *>(ws_al);
+  unsigned *tile_start = reinterpret_cast<unsigned *>(ws_al + round_up(G * sizeof(GroupDesc), 256));
+
+  const DeviceInfo &di = device_info();
+  hipLaunchKernelGGL(grouped_setup_kernel, dim3(1), dim3(64), 0, stream, descs, tile_start, A, B, C, D, la, lo,
+                     static_cast<const float *>(alpha.data.ptr), static_cast<int>(alpha.data.numel()),
+                     static_cast<const float *>(beta.data.ptr), static_cast<int>(beta.data.numel()),
+                     static_cast<unsigned>(G), transa ? 1 : 0, transb ? 1 : 0,
+                     static_cast<unsigned>(dtype_bits(d_dtype) / 8), has_c);
+  NVTE_CHECK_HIP(hipGetLastError());
+
+  GemmArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.groups = descs;
+  g.group_tile_start = tile_start;
+  g.num_groups = static_cast<unsigned>(G);
+  g.d_dtype = d_dtype;
+  unsigned cus = static_cast<unsigned>(di.num_cus);
+  if (config != nullptr) {
+    const int want = static_cast<const GroupedMatmulConfig *>(config)->sm_count;
+    if (want > 0) cus = std::min(cus, static_cast<unsigned>(want));
+  }
+  g.grid = cus;  // persistent: the tile count is only known on the device
+  (void)api;
+  launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
+}
+
+}  // namespace
 }  // namespace te
 
 using namespace te;
@@ -1017,6 +1383,73 @@ void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTET
     }
     gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, lookup(workspace), *alpha, *beta,
               stream);
+  });
+}
+
+size_t nvte_get_grouped_gemm_setup_workspace_size(size_t num_tensors) { return grouped_setup_bytes(num_tensors); }
+
+void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
+                       const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha, const NVTETensor beta,
+                       NVTETensor workspace_setup, NVTETensor workspace_cublas, NVTEGroupedMatmulConfig config,
+                       hipStream_t stream) {
+  api_guard("nvte_grouped_gemm", [&] {
+    (void)workspace_cublas;
+    GroupedCall call;
+    call.A = lookup_grouped_checked(A);
+    call.B = lookup_grouped_checked(B);
+    call.C = C ? lookup_grouped_checked(C) : nullptr;
+    call.D = lookup_grouped_checked(D);
+    grouped_gemm_impl("nvte_grouped_gemm", call, call.A->num_tensors, transa != 0, transb != 0, alpha, beta,
+                      workspace_setup, config, stream);
+  });
+}
+
+void nvte_grouped_gemm_with_discrete_inputA(const NVTETensor *A_list, size_t num_a_tensors, int transa,
+                                            const NVTEGroupedTensor B, int transb, const NVTEGroupedTensor C,
+                                            NVTEGroupedTensor D, const NVTETensor alpha, const NVTETensor beta,
+                                            NVTETensor workspace_setup, NVTETensor workspace_cublas,
+                                            NVTEGroupedMatmulConfig config, hipStream_t stream) {
+  api_guard("nvte_grouped_gemm_with_discrete_inputA", [&] {
+    (void)workspace_cublas;
+    NVTE_CHECK(A_list != nullptr, "Grouped GEMM: A_list is null.");
+    NVTE_CHECK(num_a_tensors > 0, "Grouped GEMM: num_a_tensors must be > 0.");
+    GroupedCall call;
+    call.a_list = A_list;
+    call.B = lookup_grouped_checked(B);
+    call.C = C ? lookup_grouped_checked(C) : nullptr;
+    call.D = lookup_grouped_checked(D);
+    NVTE_CHECK(call.B->num_tensors == num_a_tensors, "Grouped GEMM: A_list must have num_tensors (",
+               call.B->num_tensors, ") entries, got ", num_a_tensors);
+    grouped_gemm_impl("nvte_grouped_gemm_with_discrete_inputA", call, num_a_tensors, transa != 0, transb != 0,
+                      alpha, beta, workspace_setup, config, stream);
+  });
+}
+
+void nvte_grouped_gemm_with_discrete_out(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B,
+                                         int transb, const NVTETensor *C_list, size_t num_c_tensors,
+                                         NVTETensor *D_list, size_t num_d_tensors, const NVTETensor alpha,
+                                         const NVTETensor beta, NVTETensor workspace_setup,
+                                         NVTETensor workspace_cublas, NVTEGroupedMatmulConfig config,
+                                         hipStream_t stream) {
+  api_guard("nvte_grouped_gemm_with_discrete_out", [&] {
+    (void)workspace_cublas;
+    NVTE_CHECK(D_list != nullptr, "Grouped GEMM: D_list is null.");
+    NVTE_CHECK(num_d_tensors > 0, "Grouped GEMM: num_d_tensors must be > 0.");
+    if (num_c_tensors > 0) NVTE_CHECK(C_list != nullptr, "Grouped GEMM: C_list is null but num_c_tensors > 0.");
+    GroupedCall call;
+    call.A = lookup_grouped_checked(A);
+    call.B = lookup_grouped_checked(B);
+    call.c_list = C_list;
+    call.d_list = D_list;
+    call.num_c = num_c_tensors;
+    const size_t G = call.A->num_tensors;
+    NVTE_CHECK(num_d_tensors == G, "Grouped GEMM: D_list must have num_tensors (", G, ") entries, got ",
+               num_d_tensors);
+    if (num_c_tensors > 0)
+      NVTE_CHECK(num_c_tensors == G, "Grouped GEMM: C_list must have num_tensors (", G, ") entries, got ",
+                 num_c_tensors);
+    grouped_gemm_impl("nvte_grouped_gemm_with_discrete_out", call, G, transa != 0, transb != 0, alpha, beta,
+                      workspace_setup, config, stream);
   });
 }
 

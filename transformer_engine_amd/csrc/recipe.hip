@@ -100,17 +100,7 @@ __global__ __launch_bounds__(512) void amax_scalar_kernel(const IT *__restrict__
   if (threadIdx.x == 0) atomic_max_nonneg(amax_out, m);
 }
 
-// ---------------------------------------------------------------- scale from amax
-__device__ __forceinline__ float scale_from_amax(float amax, float max_fp8, bool pow2, float eps,
-                                                 float value_for_inf) {
-  if (amax < eps) amax = eps;  // false for NaN
-  if (__builtin_isinf(amax) || amax == 0.f || amax != amax) return 1.f;
-  float scale = max_fp8 / amax;  // IEEE-rounded division (no fast-math in this library)
-  if (__builtin_isinf(scale)) scale = value_for_inf;
-  if (pow2) scale = __uint_as_float(__float_as_uint(scale) & 0xFF800000u);
-  return scale;
-}
-
+// ---------------------------------------------------------------- scale from amax (device_utils.h)
 __global__ void scale_from_amax_kernel(const float *amax, float *scale, float max_fp8, bool pow2,
                                        float eps, const float *noop) {
   if (noop_set(noop)) return;
