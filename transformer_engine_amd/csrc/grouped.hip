@@ -122,49 +122,40 @@ __global__ __launch_bounds__(256) void group_amax_kernel(const IT *__restrict__ 
   if (start >= active) return;
   const int64_t end = start + kAmaxChunk < active ? start + kAmaxChunk : active;
   const unsigned t_lo = member_holding(g, start), t_hi = member_holding(g, end - 1);
-  if (t_lo == t_hi) {
-    // the whole chunk belongs to one member: vector scan + one atomic
-    float m = 0.f;
-    int64_t i = start + threadIdx.x * 8;
-    if (vec_ok) {
-      float m1 = 0.f;
-      // two independent vectors in flight per iteration
-      for (; i + 256 * 8 + 8 <= end; i += 2 * 256 * 8) {
-        float f[8], h[8];
-        Load8<IT>::run(in + i, f);
-        Load8<IT>::run(in + i + 256 * 8, h);
+  // one pass per member that owns a piece of this chunk (nearly always exactly one)
+  for (unsigned t = t_lo; t <= t_hi; ++t) {
+    const Member mem = member_of(g, t);
+    const int64_t s0 = mem.off > start ? mem.off : start;
+    const int64_t mem_end = mem.off + mem.rows * mem.cols;
+    const int64_t s1 = mem_end < end ? mem_end : end;
+    if (s0 >= s1) continue;  // empty member (block-uniform)
+    float m = 0.f, m1 = 0.f;
+    // scalar head up to the next 8-element boundary, vector body, scalar tail
+    const int64_t body0 = vec_ok ? ((s0 + 7) & ~static_cast<int64_t>(7)) : s1;
+    const int64_t head_end = body0 < s1 ? body0 : s1;
+    for (int64_t e = s0 + threadIdx.x; e < head_end; e += 256) m = fmaxf(m, __builtin_fabsf(widen(in[e])));
+    int64_t i = body0 + threadIdx.x * 8;
+    for (; i + 256 * 8 + 8 <= s1; i += 2 * 256 * 8) {  // two independent vectors in flight
+      float f[8], h[8];
+      Load8<IT>::run(in + i, f);
+      Load8<IT>::run(in + i + 256 * 8, h);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          m = fmaxf(m, __builtin_fabsf(f[k]));
-          m1 = fmaxf(m1, __builtin_fabsf(h[k]));
-        }
+      for (int k = 0; k < 8; ++k) {
+        m = fmaxf(m, __builtin_fabsf(f[k]));
+        m1 = fmaxf(m1, __builtin_fabsf(h[k]));
       }
-      for (; i + 8 <= end; i += 256 * 8) {
-        float f[8];
-        Load8<IT>::run(in + i, f);
+    }
+    for (; i + 8 <= s1; i += 256 * 8) {
+      float f[8];
+      Load8<IT>::run(in + i, f);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) m = fmaxf(m, __builtin_fabsf(f[k]));
-      }
-      m = fmaxf(m, m1);
+      for (int k = 0; k < 8; ++k) m = fmaxf(m, __builtin_fabsf(f[k]));
     }
-    for (; i < end; i += 256 * 8)
-      for (int64_t e = i; e < i + 8 && e < end; ++e) m = fmaxf(m, __builtin_fabsf(widen(in[e])));
-    m = block_max<4>(m, red);
-    if (threadIdx.x == 0) atomic_max_nonneg(amax + t_lo, m);
-  } else {
-    // a member boundary inside the chunk: element-wise, flush on every member change
-    unsigned cur = member_holding(g, start + threadIdx.x < end ? start + threadIdx.x : start);
-    float m = 0.f;
-    for (int64_t i = start + threadIdx.x; i < end; i += 256) {
-      const unsigned t = member_holding(g, i);
-      if (t != cur) {
-        atomic_max_nonneg(amax + cur, m);
-        cur = t;
-        m = 0.f;
-      }
-      m = fmaxf(m, __builtin_fabsf(widen(in[i])));
-    }
-    atomic_max_nonneg(amax + cur, m);
+    if (i < s1 && i >= body0)
+      for (int64_t e = i; e < s1; ++e) m = fmaxf(m, __builtin_fabsf(widen(in[e])));
+    m = block_max<4>(fmaxf(m, m1), red);
+    if (threadIdx.x == 0) atomic_max_nonneg(amax + t, m);
+    __syncthreads();  // `red` is reused by the next member
   }
 }
 
