@@ -1,0 +1,80 @@
+"""FP8 GroupedLinear (MoE experts) forward + backward on the grouped path, member shapes on the device.
+
+Mirrors the call sequence of ``transformer_engine/pytorch/module/grouped_linear.py`` (fused grouped
+path, ``NVTE_GROUPED_LINEAR_USE_FUSED_GROUPED_GEMM=1``, :136): one grouped quantize per operand, one
+grouped GEMM per pass, ``m_splits`` never leaves the GPU.
+
+  forward   X [sum m_i, K] --group_quantize(row+col)--> X8 ;  W [G*N, K] --group_quantize (cached)--> W8
+            Y_i  = X8_i W8_i^T                      grouped GEMM "TN"
+  backward  dY --group_quantize(row+col, E5M2 under HYBRID)--> dY8
+            dX_i = dY8_i W8_i                       grouped GEMM "NN"
+            dW_i = dY8_i^T X8_i (+ main_grad_i)     grouped GEMM "NT", discrete outputs
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .grouped import (GroupedTensor, general_grouped_gemm_for_grouped_tensor, group_quantize,
+                      splits_to_offsets)
+from .recipe import Float8CurrentScaling, get_fp8_te_dtype
+from .tensor import Float8CurrentScalingQuantizer
+
+
+class GroupedLinearFP8State:
+    def __init__(self, recipe: Float8CurrentScaling, num_gemms: int, device=None):
+        if not isinstance(recipe, Float8CurrentScaling):
+            raise NotImplementedError("the grouped path implements FP8 per-tensor current scaling")
+        self.recipe, self.num_gemms = recipe, num_gemms
+        self.device = device or torch.device("cuda")
+        f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
+        mk = lambda dt: Float8CurrentScalingQuantizer(dt, self.device, force_pow_2_scales=recipe.use_power_2_scales,
+                                                      amax_epsilon=recipe.amax_epsilon)
+        self.q_input, self.q_weight, self.q_grad = mk(f), mk(f), mk(b)
+        self.weight_cache: Optional[GroupedTensor] = None
+
+
+def _hp_out(first_dims: torch.Tensor, rows: int, cols: int, G: int, dtype) -> GroupedTensor:
+    return GroupedTensor(num_tensors=G, logical_shape=(rows, cols), dtype=dtype,
+                         rowwise_data=torch.empty(rows * cols, dtype=dtype, device=first_dims.device),
+                         first_dims=first_dims, tensor_offsets=splits_to_offsets(first_dims, cols))
+
+
+def grouped_linear_forward(x: torch.Tensor, weight: torch.Tensor, first_dims: torch.Tensor,
+                           st: GroupedLinearFP8State, *, is_first_microbatch: Optional[bool] = None,
+                           needs_backward: bool = True):
+    """x [sum m_i, K] (rows already sorted by expert), weight [G*N, K] (experts stacked),
+    first_dims int64 device tensor [G].  Returns (y [sum m_i, N], saved)."""
+    G = st.num_gemms
+    K = x.shape[-1]
+    N = weight.shape[0] // G
+    st.q_input.set_usage(rowwise=True, columnwise=needs_backward)
+    x8 = group_quantize(x, st.q_input, G, first_dims=first_dims)
+    if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
+        st.q_weight.set_usage(rowwise=True, columnwise=needs_backward)
+        w8 = group_quantize(weight, st.q_weight, G)
+        if is_first_microbatch is not None:
+            st.weight_cache = w8
+    else:
+        w8 = st.weight_cache
+    out = _hp_out(first_dims, x.shape[0], N, G, x.dtype)
+    general_grouped_gemm_for_grouped_tensor(w8, x8, out, layout="TN")
+    return out.rowwise_data.view(x.shape[0], N), (x8, w8, K, N)
+
+
+def grouped_linear_backward(dy: torch.Tensor, saved, first_dims: torch.Tensor, st: GroupedLinearFP8State, *,
+                            wgrad_out: Optional[List[torch.Tensor]] = None, accumulate_wgrad: bool = False):
+    """Returns (dx [sum m_i, K], list of dW_i [N, K])."""
+    x8, w8, K, N = saved
+    G = st.num_gemms
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    st.q_grad.set_usage(rowwise=True, columnwise=True)
+    dy8 = group_quantize(dy, st.q_grad, G, first_dims=first_dims)
+    dx = _hp_out(first_dims, dy.shape[0], K, G, dy.dtype)
+    general_grouped_gemm_for_grouped_tensor(w8, dy8, dx, layout="NN")
+    if wgrad_out is None:
+        wgrad_out = [torch.empty(N, K, dtype=dy.dtype, device=dy.device) for _ in range(G)]
+        accumulate_wgrad = False
+    general_grouped_gemm_for_grouped_tensor(x8, dy8, wgrad_out, layout="NT", accumulate=accumulate_wgrad)
+    return dx.rowwise_data.view(dy.shape[0], K), wgrad_out
