@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grouped", action="store_true", help="skip the configs[4]-shaped GroupedLinear side measurement")
     return ap.parse_args()
 
 
@@ -80,6 +81,35 @@ def time_kernel(fn, iters, warm=3):
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
+
+
+def grouped_c5(dev, iters):
+    """Side measurement (not `value`): BASELINE configs[4]-shaped GroupedLinear step on ONE GPU -
+    8 experts 4096->14336, 16384 routed tokens (8192 tokens x top-2, fixed-seed ragged splits padded
+    to 16), FP8 current scaling, fwd+bwd on the grouped path with device-side splits."""
+    import numpy as np
+    from transformer_engine_amd.grouped_linear import (GroupedLinearFP8State, grouped_linear_backward,
+                                                       grouped_linear_forward)
+    from transformer_engine_amd.recipe import Float8CurrentScaling
+    G, K, N, routed = 8, 4096, 14336, 16384
+    counts = np.bincount(np.random.default_rng(1234).integers(0, G, size=routed), minlength=G)
+    m_splits = [int((c + 15) // 16 * 16) for c in counts]
+    M = sum(m_splits)
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(G * N, K, device=dev, dtype=torch.bfloat16) * 0.02
+    dy = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
+    fd = torch.tensor(m_splits, dtype=torch.int64, device=dev)
+    st = GroupedLinearFP8State(Float8CurrentScaling(), G, dev)
+    grads = [torch.zeros(N, K, device=dev, dtype=torch.bfloat16) for _ in range(G)]
+    grouped_linear_forward(x, w, fd, st, is_first_microbatch=True)     # weights quantized once, cached
+
+    def step():
+        y, saved = grouped_linear_forward(x, w, fd, st, is_first_microbatch=False)
+        grouped_linear_backward(dy, saved, fd, st, wgrad_out=grads, accumulate_wgrad=False)
+
+    ms = time_kernel(step, iters)
+    return {"workload": "8 experts 4096->14336, 16384 routed tokens, current scaling, fwd+bwd, 1 GPU",
+            "m_splits": m_splits, "ms_per_step": ms, "tflops": 6.0 * M * N * K / (ms * 1e-3) / 1e12}
 
 
 def cpu_baseline(tokens=4096, K=4096, N=14336):
@@ -287,6 +317,8 @@ def main():
             "gemm_only_tflops": 3 * gemm_flops / ((t_fprop + t_dgrad + t_wgrad) * 1e-3) / 1e12,
             "weight_quantize_ms_not_in_step": t_ct_w,
         }
+        if not args.no_grouped:
+            result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
 
