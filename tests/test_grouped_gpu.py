@@ -378,3 +378,43 @@ def test_grouped_linear_fwd_bwd_equals_per_expert_linear():
         assert torch.equal(dx[r0:r0 + m], dxi), f"dgrad member {i}"
         assert torch.equal(dws[i], gi), f"wgrad member {i}"
         r0 += m
+
+
+def test_grouped_step_replays_in_a_hip_graph_with_new_splits():
+    """Member shapes are device data: a step captured ONCE in a HIP graph must give the right answer
+    when only the CONTENTS of first_dims change between replays (same total token count)."""
+    from transformer_engine_amd.grouped_linear import (GroupedLinearFP8State, grouped_linear_backward,
+                                                       grouped_linear_forward)
+    from transformer_engine_amd.recipe import Float8CurrentScaling
+    G, K, N, M = 4, 128, 256, 512
+    x = randn_input((M, K), torch.bfloat16, 61)
+    w = randn_input((G * N, K), torch.bfloat16, 62, scale=0.05)
+    dy = randn_input((M, N), torch.bfloat16, 63)
+    fd = _dev_i64([128, 128, 128, 128])
+    st = GroupedLinearFP8State(Float8CurrentScaling(), G)
+
+    def step():
+        y, saved = grouped_linear_forward(x, w, fd, st)
+        dx, dws = grouped_linear_backward(dy, saved, fd, st)
+        return y, dx, dws
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                    # warm-up outside capture (workspace allocation)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            gy, gdx, gdws = step()
+    torch.cuda.current_stream().wait_stream(side)
+    for splits in ([128, 128, 128, 128], [16, 304, 0, 192], [512, 0, 0, 0]):
+        fd.copy_(_dev_i64(splits))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (gy.clone(), gdx.clone(), [t.clone() for t in gdws])
+        ey, edx, edws = step()                    # eager reference with the same splits
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ey) and torch.equal(got[1], edx), splits
+        for a, b, m in zip(got[2], edws, splits):
+            if m:                                  # an empty expert's fresh wgrad buffer is beta*C with beta=0
+                assert torch.equal(a, b), splits
