@@ -92,6 +92,17 @@ def lib() -> ctypes.CDLL:
                                           c.c_size_t, c.c_size_t]
         L.te_gelu_ref.restype = None
         L.te_gelu_ref.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_int]
+        L.te_norm_stats_ref.restype = None
+        L.te_norm_stats_ref.argtypes = [c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_size_t,
+                                        c.c_size_t, c.c_double]
+        L.te_norm_output_ref.restype = None
+        L.te_norm_output_ref.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_void_p,
+                                         c.c_void_p, c.c_void_p, c.c_size_t, c.c_size_t, c.c_void_p, c.c_float,
+                                         c.c_int, c.c_int]
+        L.te_norm_backward_ref.restype = None
+        L.te_norm_backward_ref.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int,
+                                           c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                                           c.c_size_t, c.c_size_t, c.c_int]
         L.te_colsum_ref.restype = None
         L.te_colsum_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_void_p]
         L.te_oracle_num_threads.restype = c.c_int
@@ -262,6 +273,44 @@ def dgelu(x: np.ndarray) -> np.ndarray:
     out = np.empty_like(x)
     lib().te_gelu_ref(_ptr(x), _ptr(out), x.size, 1)
     return out
+
+
+def norm_forward(x: np.ndarray, gamma: np.ndarray, beta, eps: float, *, scale: float = 1.0,
+                 zero_centered_gamma: bool = False, out_dtype: int = DT_F32):
+    """LayerNorm (beta given) / RMSNorm (beta None).  Returns (pre-conversion output * scale [N, H] fp32,
+    mu or None, rsigma, amax) - ref tests/cpp/operator/test_normalization.h:33-135."""
+    x = np.ascontiguousarray(x)
+    gamma = np.ascontiguousarray(gamma)
+    N, H = x.shape
+    is_ln = beta is not None
+    beta_c = np.ascontiguousarray(beta) if is_ln else None
+    mu = np.zeros(N, np.float32)
+    rs = np.zeros(N, np.float32)
+    lib().te_norm_stats_ref(int(is_ln), _ptr(x), _in_dtype(x), _ptr(mu), _ptr(rs), N, H, float(eps))
+    out = np.empty((N, H), np.float32)
+    amax = np.zeros(1, np.float32)
+    lib().te_norm_output_ref(int(is_ln), _ptr(x), _ptr(gamma), _ptr(beta_c) if is_ln else None, _in_dtype(x),
+                             _in_dtype(gamma), _ptr(out), _ptr(mu), _ptr(rs), N, H, _ptr(amax),
+                             ctypes.c_float(scale), int(zero_centered_gamma), out_dtype)
+    return out, (mu if is_ln else None), rs, amax[0]
+
+
+def norm_backward(dz: np.ndarray, x: np.ndarray, mu, rsigma: np.ndarray, gamma: np.ndarray, *, add=None,
+                  zero_centered_gamma: bool = False):
+    """Returns (dx, dgamma, dbeta or None) in fp32 - ref test_normalization.h:138-190."""
+    dz, x, gamma = np.ascontiguousarray(dz), np.ascontiguousarray(x), np.ascontiguousarray(gamma)
+    N, H = x.shape
+    is_ln = mu is not None
+    dx = np.empty((N, H), np.float32)
+    dg = np.empty(H, np.float32)
+    db = np.empty(H, np.float32) if is_ln else None
+    add_c = np.ascontiguousarray(add) if add is not None else None
+    mu_c = np.ascontiguousarray(mu, np.float32) if is_ln else None
+    rs_c = np.ascontiguousarray(rsigma, np.float32)
+    lib().te_norm_backward_ref(int(is_ln), _ptr(dz), _ptr(add_c) if add_c is not None else None, _ptr(x),
+                               _in_dtype(x), _in_dtype(gamma), _ptr(mu_c) if is_ln else None, _ptr(rs_c), _ptr(gamma),
+                               _ptr(dx), _ptr(dg), _ptr(db) if is_ln else None, N, H, int(zero_centered_gamma))
+    return dx, dg, db
 
 
 def colsum(x: np.ndarray) -> np.ndarray:

@@ -426,6 +426,84 @@ void te_gelu_ref(const float *in, float *out, size_t n, int mode) {
   }
 }
 
+/* ------------------------------------------------------------------ LayerNorm / RMSNorm
+ * Restatement of the reference's own host oracle, ref tests/cpp/operator/test_normalization.h:
+ * compute_ref_stats :33-57, compute_gamma :60-92 (non-cuDNN branch), compute_ref_output :95-135,
+ * compute_ref_backward :138-190.  fp32 arithmetic in the same order. */
+static inline float round_out(float v, int out_dtype) {
+  if (out_dtype == 6) { uint32_t u = ((uint32_t)te_float_to_bf16(v)) << 16; float f; memcpy(&f, &u, 4); return f; }
+  if (out_dtype == 5) return te_half_to_float(te_float_to_half(v));
+  return v;
+}
+
+void te_norm_stats_ref(int is_ln, const void *x, int dtype, float *mu, float *rsigma, size_t N, size_t H,
+                       double epsilon) {
+  for (size_t i = 0; i < N; ++i) {
+    float sum = 0.f, m = 0.f;
+    for (size_t j = 0; j < H; ++j) sum += load_in(x, i * H + j, dtype);
+    if (is_ln) { mu[i] = sum / H; m = mu[i]; }
+    float sum_sq = 0.f;
+    for (size_t j = 0; j < H; ++j) {
+      const float cur = load_in(x, i * H + j, dtype);
+      sum_sq += (cur - m) * (cur - m);
+    }
+    rsigma[i] = (float)(1.0 / sqrt((double)((sum_sq / H) + epsilon)));
+  }
+}
+
+/* out[i] = the fp32 value BEFORE the conversion to the output type (tmp * scale); amax: on tmp when
+ * scale != 1 (FP8 paths), else on tmp rounded to out_dtype. */
+void te_norm_output_ref(int is_ln, const void *x, const void *gamma, const void *beta, int dtype, int wdtype,
+                        float *out, const float *mu, const float *rsigma, size_t N, size_t H, float *amax,
+                        float scale, int zero_centered_gamma, int out_dtype) {
+  float current_max = 0.f;
+  for (size_t i = 0; i < N; ++i)
+    for (size_t j = 0; j < H; ++j) {
+      const float cur = load_in(x, i * H + j, dtype);
+      float g = load_in(gamma, j, wdtype);
+      if (zero_centered_gamma) g += 1.f;
+      float tmp;
+      if (is_ln) tmp = (cur - mu[i]) * rsigma[i] * g + load_in(beta, j, wdtype);
+      else tmp = cur * rsigma[i] * g;
+      out[i * H + j] = tmp * scale;
+      if (scale != 1.f) current_max = fmaxf(current_max, fabsf(tmp));
+      else current_max = fmaxf(current_max, fabsf(round_out(tmp, out_dtype)));
+    }
+  if (amax) *amax = current_max;
+}
+
+void te_norm_backward_ref(int is_ln, const void *dz, const void *add, const void *x, int dtype, int wdtype,
+                          const float *mu, const float *rsigma, const void *gamma, float *dx, float *dgamma,
+                          float *dbeta, size_t N, size_t H, int zero_centered_gamma) {
+  for (size_t j = 0; j < H; ++j) { dgamma[j] = 0.f; if (dbeta) dbeta[j] = 0.f; }
+  for (size_t i = 0; i < N; ++i) {
+    const float local_mu = is_ln ? mu[i] : 0.f;
+    float mdy = 0.f, mdyy = 0.f;
+    for (size_t j = 0; j < H; ++j) {
+      const float xv = load_in(x, i * H + j, dtype);
+      const float y = (xv - local_mu) * rsigma[i];
+      float g = load_in(gamma, j, wdtype);
+      if (zero_centered_gamma) g += 1.f;
+      const float dzv = load_in(dz, i * H + j, wdtype);
+      const float dy = g * dzv;
+      dgamma[j] += y * dzv;
+      if (is_ln) { dbeta[j] += dzv; mdy += dy; }
+      mdyy += dy * y;
+    }
+    mdy /= H;
+    mdyy /= H;
+    for (size_t j = 0; j < H; ++j) {
+      const float xv = load_in(x, i * H + j, dtype);
+      const float y = (xv - local_mu) * rsigma[i];
+      float g = load_in(gamma, j, wdtype);
+      if (zero_centered_gamma) g += 1.f;
+      const float dy = g * load_in(dz, i * H + j, wdtype);
+      const float a = add ? load_in(add, i * H + j, wdtype) : 0.f;
+      dx[i * H + j] = a + rsigma[i] * (dy - mdyy * y - mdy);
+    }
+  }
+}
+
 int te_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

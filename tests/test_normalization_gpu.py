@@ -1,0 +1,144 @@
+"""GPU parity of LayerNorm / RMSNorm forward (with fused FP8 output) and backward.
+
+Oracle: restatement of the reference's own host oracle (tests/cpp/operator/test_normalization.h),
+shapes and tolerances from tests/cpp/operator/test_normalization.cu:205-237: mu / rsigma rtol 5e-5,
+output per getTolerances(otype) (fp32 1e-6/8e-6... bf16 1e-5/8e-3, fp8 1e-2-ish); FP8 bytes are compared
+after dequantisation allowing ONE code step where the fp32 pre-quantisation values differ in the last
+bits (the sums are taken in a different order than the serial reference loop); backward atol/rtol 5e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import FMT, randn_input, to_oracle_input, u8
+from transformer_engine_amd.normalization import layernorm_bwd, layernorm_fwd, rmsnorm_bwd, rmsnorm_fwd
+from transformer_engine_amd.tensor import DType, Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantizer
+
+pytestmark = pytest.mark.gpu
+E4, E5 = DType.kFloat8E4M3, DType.kFloat8E5M2
+
+SHAPES = [(71, 229), (29, 541), (768, 6144), (2048, 12288), (256, 4096), (64, 8192)]   # first four: the reference's
+
+
+def _inputs(N, H, dtype, seed):
+    x = randn_input((N, H), dtype, seed) * 1.5 + 0.25
+    g = randn_input((H,), dtype, seed + 1) * 0.5 + 1.0
+    b = randn_input((H,), dtype, seed + 2) * 0.25
+    return x.contiguous(), g.contiguous(), b.contiguous()
+
+
+@pytest.mark.parametrize("N,H", SHAPES)
+@pytest.mark.parametrize("kind", ["ln", "rms"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("zero_centered", [False, True])
+def test_norm_fwd_high_precision(N, H, kind, dtype, zero_centered):
+    if dtype == torch.float32 and N * H > 8e6:
+        pytest.skip("large fp32 case adds nothing over bf16")
+    x, g, b = _inputs(N, H, dtype, 3)
+    if kind == "ln":
+        out, mu, rs = layernorm_fwd(x, g, b, 1e-5, zero_centered_gamma=zero_centered)
+    else:
+        out, mu, rs = rmsnorm_fwd(x, g, 1e-5, zero_centered_gamma=zero_centered)
+    torch.cuda.synchronize()
+    ref, rmu, rrs, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g),
+                                           to_oracle_input(b) if kind == "ln" else None, 1e-5,
+                                           zero_centered_gamma=zero_centered)
+    assert np.allclose(rs.cpu().numpy(), rrs, rtol=5e-5, atol=1e-6)
+    if kind == "ln":
+        assert np.allclose(mu.cpu().numpy(), rmu, rtol=5e-5, atol=1e-6)
+    if dtype == torch.float32:
+        assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    else:   # bf16: one rounding of the output (getTolerances(bf16): atol 1e-5, rtol 8e-3)
+        assert np.allclose(out.float().cpu().numpy(), ref, rtol=8e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,H", [(71, 229), (768, 6144), (256, 4096), (2048, 12288)])
+@pytest.mark.parametrize("kind", ["ln", "rms"])
+@pytest.mark.parametrize("fmt", [E4, E5])
+def test_norm_fwd_fp8_delayed_scaling(N, H, kind, fmt):
+    x, g, b = _inputs(N, H, torch.bfloat16, 5)
+    scale = torch.full((1,), 13.5, device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    q = Float8Quantizer(scale, amax, fmt)
+    if kind == "ln":
+        out, mu, rs = layernorm_fwd(x, g, b, 1e-5, quantizer=q)
+    else:
+        out, mu, rs = rmsnorm_fwd(x, g, 1e-5, quantizer=q)
+    torch.cuda.synchronize()
+    ref, _, rrs, ref_amax = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g),
+                                                to_oracle_input(b) if kind == "ln" else None, 1e-5, scale=13.5)
+    assert np.allclose(rs.cpu().numpy(), rrs, rtol=5e-5, atol=1e-6)
+    assert np.isclose(amax.item(), ref_amax, rtol=1e-5)                      # fp32 tolerance, as the reference
+    assert out._scale_inv.item() == np.float32(1.0) / np.float32(13.5)
+    got = oracle.fp8_to_float(u8(out._data), FMT[fmt])
+    want = oracle.fp8_to_float(oracle.float_to_fp8(ref, FMT[fmt]), FMT[fmt])
+    # identical codes except where the fp32 value sits on a rounding boundary: at most one code step
+    # (relative spacing 2^-3 for e4m3, 2^-2 for e5m2), on a tiny fraction of the elements
+    step = 2.0 ** -3 if fmt == E4 else 2.0 ** -2
+    sub = 2.0 ** -9 if fmt == E4 else 2.0 ** -16          # spacing of the subnormal codes
+    diff = np.abs(got - want)
+    # ... or inside the reference's own FP8 output tolerance (getTolerances: atol 1e-2, rtol 1e-2), which
+    # covers values that cancel to ~0 in (x - mu)
+    assert (diff <= np.maximum(step * np.abs(want) + sub, 1e-2 + 1e-2 * np.abs(want))).all()
+    assert (diff != 0).mean() < 2e-3
+    # the columnwise copy is the byte transpose of the rowwise payload
+    assert np.array_equal(u8(out._transpose), u8(out._data).T)
+
+
+def test_norm_fwd_mxfp8_and_current_scaling_outputs():
+    N, H = 256, 1024
+    x, g, b = _inputs(N, H, torch.bfloat16, 7)
+    hp, _, _ = rmsnorm_fwd(x, g, 1e-5)
+    # MXFP8: the normalized rows (in the input dtype) quantized by the MXFP8 kernel
+    qm = MXFP8Quantizer(E4)
+    out, _, _ = rmsnorm_fwd(x, g, 1e-5, quantizer=qm)
+    ref = qm(hp)
+    torch.cuda.synchronize()
+    assert torch.equal(out._rowwise_data, ref._rowwise_data) and torch.equal(out._rowwise_scale_inv, ref._rowwise_scale_inv)
+    assert torch.equal(out._columnwise_data, ref._columnwise_data)
+    # current scaling: norm to high precision, then the amax -> scale -> cast sequence
+    qc = Float8CurrentScalingQuantizer(E4, torch.device("cuda"))
+    out, _, _ = rmsnorm_fwd(x, g, 1e-5, quantizer=qc)
+    ref = qc(hp)
+    torch.cuda.synchronize()
+    assert torch.equal(out._data, ref._data) and torch.equal(out._scale_inv, ref._scale_inv)
+
+
+@pytest.mark.parametrize("N,H", [(71, 229), (29, 541), (768, 6144), (512, 8192), (2048, 12288)])
+@pytest.mark.parametrize("kind", ["ln", "rms", "rms_add"])
+@pytest.mark.parametrize("zero_centered", [False, True])
+def test_norm_bwd(N, H, kind, zero_centered):
+    dtype = torch.bfloat16 if H != 541 else torch.float32
+    x, g, b = _inputs(N, H, dtype, 9)
+    dz = randn_input((N, H), dtype, 12)
+    add = randn_input((N, H), dtype, 13) if kind == "rms_add" else None
+    if kind == "ln":
+        _, mu, rs = layernorm_fwd(x, g, b, 1e-5, zero_centered_gamma=zero_centered)
+        dx, dg, db = layernorm_bwd(dz, x, mu, rs, g, zero_centered_gamma=zero_centered)
+    else:
+        _, mu, rs = rmsnorm_fwd(x, g, 1e-5, zero_centered_gamma=zero_centered)
+        dx, dg = rmsnorm_bwd(dz, x, rs, g, zero_centered_gamma=zero_centered, add=add)
+        db = None
+    torch.cuda.synchronize()
+    rdx, rdg, rdb = oracle.norm_backward(to_oracle_input(dz), to_oracle_input(x),
+                                         mu.cpu().numpy() if kind == "ln" else None, rs.cpu().numpy(),
+                                         to_oracle_input(g), add=to_oracle_input(add) if add is not None else None,
+                                         zero_centered_gamma=zero_centered)
+    # reference test tolerance 5e-4 abs/rel on values of its dtype; bf16 results carry one bf16 rounding
+    # (2^-8 relative), dgamma/dbeta sums over N rows are compared relative to the column's absolute sum
+    tol = 5e-4 if dtype == torch.float32 else 2 ** -7
+    assert np.allclose(dx.float().cpu().numpy(), rdx, rtol=tol, atol=tol)
+    scale_g = np.abs(rdg).max() + 1.0
+    assert np.allclose(dg.float().cpu().numpy(), rdg, rtol=tol, atol=tol * scale_g)
+    if db is not None:
+        assert np.allclose(db.float().cpu().numpy(), rdb, rtol=tol, atol=tol * (np.abs(rdb).max() + 1.0))
+
+
+def test_norm_argument_errors():
+    from transformer_engine_amd import NVTEError
+    x, g, b = _inputs(16, 64, torch.bfloat16, 1)
+    with pytest.raises(NVTEError, match="Gamma must have the same hidden size"):
+        rmsnorm_fwd(x, g[:32].contiguous(), 1e-5)
+    with pytest.raises(NVTEError, match="Epsilon must be non-negative"):
+        rmsnorm_fwd(x, g, -1.0)

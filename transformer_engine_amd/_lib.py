@@ -177,6 +177,15 @@ _SIGS = {
                                                  _P, _P, _P, _P]),
     "nvte_grouped_bias_add": (_V, [_P, _P, _P]),
     "nvte_grouped_scaled_bias_add": (_V, [_P, _P, _P, _P]),
+    # normalization.h
+    "nvte_layernorm_fwd": (_V, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _B, _P]),
+    "nvte_layernorm_bwd": (_V, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _B, _P]),
+    "nvte_rmsnorm_fwd": (_V, [_P, _P, _F, _P, _P, _P, _I, _B, _P]),
+    "nvte_rmsnorm_bwd": (_V, [_P, _P, _P, _P, _P, _P, _P, _I, _B, _P]),
+    "nvte_rmsnorm_bwd_add": (_V, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _B, _P]),
+    "nvte_enable_cudnn_norm_fwd": (_V, [_B]),
+    "nvte_enable_cudnn_norm_bwd": (_V, [_B]),
+    "nvte_enable_zero_centered_gamma_in_weight_dtype": (_V, [_B]),
     # swizzle.h
     "nvte_swizzle_scaling_factors": (_V, [_P, _P, _P]),
     "nvte_multi_tensor_swizzle_scaling_factors": (_V, [C.POINTER(_P), C.POINTER(_P), _SZ, _P]),

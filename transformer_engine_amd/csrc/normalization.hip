@@ -1,0 +1,674 @@
+// LayerNorm / RMSNorm forward with fused FP8 quantization (scale in, amax + scale_inv out) and
+// backward.  HBM-bound: forward 2 B read + 1 B (FP8) written per bf16 element, backward 4 B read +
+// 2 B written.
+//
+// Replaces (behaviour, not structure):
+//   ref common/normalization/layernorm/ln_api.cpp:24-229, rmsnorm/rmsnorm_api.cpp:24-290 (entry
+//       points, checks, workspace-query protocol, transpose after an FP8 forward),
+//       layernorm/ln_fwd_kernels.cuh, rmsnorm/rmsnorm_fwd_kernels.cuh:18-160 (row statistics,
+//       gamma(+1), amax on the pre-scale value for FP8 / on the rounded value otherwise, scale_inv),
+//       layernorm/ln_bwd_kernels.cuh, rmsnorm/rmsnorm_bwd_kernels.cuh (dx, two-stage dgamma/dbeta).
+//
+// MI355X design: one 256-thread workgroup per row at a time, persistent over rows (grid = a few
+// workgroups per CU); thread t owns the 8-element vectors v*256 + t of the row (16-byte loads: a
+// wave reads 1 KiB contiguous), the row lives in registers between the statistics and the output,
+// gamma / beta live in registers for the whole kernel.  Row sums: wave shuffles + 4 floats of LDS,
+// double-buffered so that each reduction costs ONE barrier.  H up to 16384 (NV = 8 vectors per
+// thread); other shapes (H % 8 != 0, unaligned, larger) take a scalar three-pass kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "common.h"
+#include "device_utils.h"
+#include "transformer_engine/normalization.h"
+#include "transformer_engine/transpose.h"
+
+namespace te {
+namespace {
+
+// ---------------------------------------------------------------- 8-element typed access
+__device__ __forceinline__ void load8(const void *base, size_t idx, int dtype, float (&f)[8]) {
+  switch (dtype) {
+    case kNVTEBFloat16: Load8<bf16_t>::run(static_cast<const bf16_t *>(base) + idx, f); break;
+    case kNVTEFloat16: Load8<f16_t>::run(static_cast<const f16_t *>(base) + idx, f); break;
+    default: Load8<float>::run(static_cast<const float *>(base) + idx, f); break;
+  }
+}
+// plain (cached) loads for the small per-column vectors
+__device__ __forceinline__ float load1(const void *base, size_t idx, int dtype) {
+  switch (dtype) {
+    case kNVTEBFloat16: return widen(static_cast<const bf16_t *>(base)[idx]);
+    case kNVTEFloat16: return widen(static_cast<const f16_t *>(base)[idx]);
+    default: return static_cast<const float *>(base)[idx];
+  }
+}
+__device__ __forceinline__ void store1(void *base, size_t idx, int dtype, float v) {
+  switch (dtype) {
+    case kNVTEBFloat16: narrow(v, static_cast<bf16_t *>(base)[idx]); break;
+    case kNVTEFloat16: narrow(v, static_cast<f16_t *>(base)[idx]); break;
+    case kNVTEFloat8E4M3: static_cast<uint8_t *>(base)[idx] = cvt1_fp8<Fp8::E4M3>(v); break;
+    case kNVTEFloat8E5M2: static_cast<uint8_t *>(base)[idx] = cvt1_fp8<Fp8::E5M2>(v); break;
+    default: static_cast<float *>(base)[idx] = v; break;
+  }
+}
+// value after rounding to the output dtype (amax of a non-FP8 output, ref rmsnorm_fwd_kernels.cuh:113-117)
+__device__ __forceinline__ float round_to(float v, int dtype) {
+  switch (dtype) {
+    case kNVTEBFloat16: { bf16_t o; narrow(v, o); return widen(o); }
+    case kNVTEFloat16: { f16_t o; narrow(v, o); return widen(o); }
+    default: return v;
+  }
+}
+__device__ __forceinline__ void store8(void *base, size_t idx, int dtype, const float (&v)[8]) {
+  switch (dtype) {
+    case kNVTEFloat8E4M3: {
+      u32x2 o = {cvt4_fp8<Fp8::E4M3>(v[0], v[1], v[2], v[3]), cvt4_fp8<Fp8::E4M3>(v[4], v[5], v[6], v[7])};
+      *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(base) + idx) = o;
+      break;
+    }
+    case kNVTEFloat8E5M2: {
+      u32x2 o = {cvt4_fp8<Fp8::E5M2>(v[0], v[1], v[2], v[3]), cvt4_fp8<Fp8::E5M2>(v[4], v[5], v[6], v[7])};
+      *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(base) + idx) = o;
+      break;
+    }
+    case kNVTEBFloat16: {
+      bf16_t o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) narrow(v[k], o[k]);
+      *reinterpret_cast<u32x4 *>(static_cast<bf16_t *>(base) + idx) = *reinterpret_cast<const u32x4 *>(o);
+      break;
+    }
+    case kNVTEFloat16: {
+      f16_t o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) narrow(v[k], o[k]);
+      *reinterpret_cast<u32x4 *>(static_cast<f16_t *>(base) + idx) = *reinterpret_cast<const u32x4 *>(o);
+      break;
+    }
+    default: {
+      f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+      float *p = static_cast<float *>(base) + idx;
+      *reinterpret_cast<f32x4 *>(p) = lo;
+      *reinterpret_cast<f32x4 *>(p + 4) = hi;
+      break;
+    }
+  }
+}
+
+// Sum of (a, b) over the 256 threads of the workgroup, result in every thread.  `red` has
+// 2 x 4 x 2 floats; `phase` alternates so that consecutive reductions need one barrier each.
+__device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[4][2], unsigned &phase) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  const unsigned w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0) {
+    red[phase][w][0] = a;
+    red[phase][w][1] = b;
+  }
+  __syncthreads();
+  a = red[phase][0][0] + red[phase][1][0] + red[phase][2][0] + red[phase][3][0];
+  b = red[phase][0][1] + red[phase][1][1] + red[phase][2][1] + red[phase][3][1];
+  phase ^= 1u;
+}
+
+struct NormFwdArgs {
+  const void *x, *gamma, *beta;
+  void *z;
+  float *mu, *rs;
+  const float *scale;
+  float *amax, *scale_inv;
+  unsigned rows, cols;
+  float eps;
+  int x_dtype, w_dtype, z_dtype;
+  int zero_centered;
+};
+
+template <int NV, bool LN>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
+  __shared__ float red[2][4][2];
+  __shared__ float red_max[4];
+  unsigned phase = 0;
+  const unsigned tid = threadIdx.x;
+  const bool fp8_out = a.z_dtype == kNVTEFloat8E4M3 || a.z_dtype == kNVTEFloat8E5M2;
+  const float scale = (fp8_out && a.scale) ? *a.scale : 1.f;
+  const float rn = 1.f / static_cast<float>(a.cols);
+  float g[NV][8], b[NV][8];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const unsigned c = (v * 256 + tid) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      g[v][k] = c < a.cols ? load1(a.gamma, c + k, a.w_dtype) + (a.zero_centered ? 1.f : 0.f) : 0.f;
+      b[v][k] = (LN && c < a.cols) ? load1(a.beta, c + k, a.w_dtype) : 0.f;
+    }
+  }
+  float amax = 0.f;
+  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const size_t base = static_cast<size_t>(row) * a.cols;
+    float x[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const unsigned c = (v * 256 + tid) * 8;
+      if (c < a.cols) {
+        load8(a.x, base + c, a.x_dtype, x[v]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[v][k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s1 += x[v][k];
+        if constexpr (!LN) s2 += x[v][k] * x[v][k];
+      }
+    }
+    block_sum2(s1, s2, red, phase);
+    float mean = 0.f;
+    if constexpr (LN) {
+      // second moment about the mean, from the registers (ref test_normalization.h:44-57)
+      mean = s1 * rn;
+      float m2 = 0.f, zero = 0.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const unsigned c = (v * 256 + tid) * 8;
+        if (c < a.cols) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) m2 += (x[v][k] - mean) * (x[v][k] - mean);
+        }
+      }
+      block_sum2(m2, zero, red, phase);
+      s2 = m2;
+    }
+    const float rs = rsqrtf(s2 * rn + a.eps);
+    if (tid == 0) {
+      if constexpr (LN) a.mu[row] = mean;
+      a.rs[row] = rs;
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const unsigned c = (v * 256 + tid) * 8;
+      if (c >= a.cols) continue;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float t = (x[v][k] - mean) * rs * g[v][k] + b[v][k];
+        if (fp8_out) {
+          amax = fmaxf(amax, __builtin_fabsf(t));
+          t *= scale;
+        } else if (a.amax) {
+          amax = fmaxf(amax, __builtin_fabsf(round_to(t, a.z_dtype)));
+        }
+        o[k] = t;
+      }
+      store8(a.z, base + c, a.z_dtype, o);
+    }
+  }
+  if (a.amax) {
+    amax = block_max<4>(amax, red_max);
+    if (tid == 0) atomic_max_nonneg(a.amax, amax);
+  }
+  if (fp8_out && blockIdx.x == 0 && tid == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
+}
+
+// Any shape / alignment: three scalar passes over the row.
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_fwd_general_kernel(const NormFwdArgs a) {
+  __shared__ float red[2][4][2];
+  __shared__ float red_max[4];
+  unsigned phase = 0;
+  const unsigned tid = threadIdx.x;
+  const bool fp8_out = a.z_dtype == kNVTEFloat8E4M3 || a.z_dtype == kNVTEFloat8E5M2;
+  const float scale = (fp8_out && a.scale) ? *a.scale : 1.f;
+  const float rn = 1.f / static_cast<float>(a.cols);
+  float amax = 0.f;
+  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const size_t base = static_cast<size_t>(row) * a.cols;
+    float s1 = 0.f, s2 = 0.f;
+    for (unsigned c = tid; c < a.cols; c += 256) {
+      const float x = load1(a.x, base + c, a.x_dtype);
+      s1 += x;
+      if constexpr (!LN) s2 += x * x;
+    }
+    block_sum2(s1, s2, red, phase);
+    float mean = 0.f;
+    if constexpr (LN) {
+      mean = s1 * rn;
+      float m2 = 0.f, zero = 0.f;
+      for (unsigned c = tid; c < a.cols; c += 256) {
+        const float d = load1(a.x, base + c, a.x_dtype) - mean;
+        m2 += d * d;
+      }
+      block_sum2(m2, zero, red, phase);
+      s2 = m2;
+    }
+    const float rs = rsqrtf(s2 * rn + a.eps);
+    if (tid == 0) {
+      if constexpr (LN) a.mu[row] = mean;
+      a.rs[row] = rs;
+    }
+    for (unsigned c = tid; c < a.cols; c += 256) {
+      const float gm = load1(a.gamma, c, a.w_dtype) + (a.zero_centered ? 1.f : 0.f);
+      float t = (load1(a.x, base + c, a.x_dtype) - mean) * rs * gm + (LN ? load1(a.beta, c, a.w_dtype) : 0.f);
+      if (fp8_out) {
+        amax = fmaxf(amax, __builtin_fabsf(t));
+        t *= scale;
+      } else if (a.amax) {
+        amax = fmaxf(amax, __builtin_fabsf(round_to(t, a.z_dtype)));
+      }
+      store1(a.z, base + c, a.z_dtype, t);
+    }
+  }
+  if (a.amax) {
+    amax = block_max<4>(amax, red_max);
+    if (tid == 0) atomic_max_nonneg(a.amax, amax);
+  }
+  if (fp8_out && blockIdx.x == 0 && tid == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
+}
+
+// ---------------------------------------------------------------- backward
+struct NormBwdArgs {
+  const void *dz, *x, *gamma, *add;
+  const float *mu, *rs;
+  void *dx;
+  float *part;  // [grid][2][cols] fp32 partial dgamma (and dbeta)
+  unsigned rows, cols;
+  int x_dtype, w_dtype;
+  int zero_centered;
+};
+
+// dx = rs * (dy - mean(dy*y) * y - mean(dy)) (+ add), dy = gamma' * dz, y = (x - mu) * rs
+// (ref tests/cpp/operator/test_normalization.h:140-190); per-workgroup partial dgamma / dbeta.
+template <int NV, bool LN>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
+  __shared__ float red[2][4][2];
+  unsigned phase = 0;
+  const unsigned tid = threadIdx.x;
+  const float rn = 1.f / static_cast<float>(a.cols);
+  float g[NV][8], dg[NV][8], db[NV][8];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const unsigned c = (v * 256 + tid) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      g[v][k] = c < a.cols ? load1(a.gamma, c + k, a.w_dtype) + (a.zero_centered ? 1.f : 0.f) : 0.f;
+      dg[v][k] = 0.f;
+      db[v][k] = 0.f;
+    }
+  }
+  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const size_t base = static_cast<size_t>(row) * a.cols;
+    const float mean = LN ? a.mu[row] : 0.f, rs = a.rs[row];
+    float y[NV][8], dy[NV][8];
+    float sdy = 0.f, sdyy = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const unsigned c = (v * 256 + tid) * 8;
+      float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dzv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (c < a.cols) {
+        load8(a.x, base + c, a.x_dtype, xv);
+        load8(a.dz, base + c, a.w_dtype, dzv);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        y[v][k] = c < a.cols ? (xv[k] - mean) * rs : 0.f;
+        dy[v][k] = g[v][k] * dzv[k];
+        dg[v][k] += y[v][k] * dzv[k];
+        if constexpr (LN) {
+          db[v][k] += dzv[k];
+          sdy += dy[v][k];
+        }
+        sdyy += dy[v][k] * y[v][k];
+      }
+    }
+    block_sum2(sdy, sdyy, red, phase);
+    const float mdy = sdy * rn, mdyy = sdyy * rn;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const unsigned c = (v * 256 + tid) * 8;
+      if (c >= a.cols) continue;
+      float o[8], ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.add) load8(a.add, base + c, a.w_dtype, ad);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = ad[k] + rs * (dy[v][k] - mdyy * y[v][k] - mdy);
+      store8(a.dx, base + c, a.x_dtype, o);
+    }
+  }
+  float *pg = a.part + static_cast<size_t>(blockIdx.x) * 2 * a.cols;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const unsigned c = (v * 256 + tid) * 8;
+    if (c >= a.cols) continue;
+    f32x4 lo = {dg[v][0], dg[v][1], dg[v][2], dg[v][3]}, hi = {dg[v][4], dg[v][5], dg[v][6], dg[v][7]};
+    *reinterpret_cast<f32x4 *>(pg + c) = lo;
+    *reinterpret_cast<f32x4 *>(pg + c + 4) = hi;
+    if constexpr (LN) {
+      f32x4 l2 = {db[v][0], db[v][1], db[v][2], db[v][3]}, h2 = {db[v][4], db[v][5], db[v][6], db[v][7]};
+      *reinterpret_cast<f32x4 *>(pg + a.cols + c) = l2;
+      *reinterpret_cast<f32x4 *>(pg + a.cols + c + 4) = h2;
+    }
+  }
+}
+
+template <bool LN>
+__global__ __launch_bounds__(256) void norm_bwd_general_kernel(const NormBwdArgs a) {
+  __shared__ float red[2][4][2];
+  unsigned phase = 0;
+  const unsigned tid = threadIdx.x;
+  const float rn = 1.f / static_cast<float>(a.cols);
+  float *pg = a.part + static_cast<size_t>(blockIdx.x) * 2 * a.cols;
+  for (unsigned c = tid; c < a.cols; c += 256) {
+    pg[c] = 0.f;
+    pg[a.cols + c] = 0.f;
+  }
+  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const size_t base = static_cast<size_t>(row) * a.cols;
+    const float mean = LN ? a.mu[row] : 0.f, rs = a.rs[row];
+    float sdy = 0.f, sdyy = 0.f;
+    for (unsigned c = tid; c < a.cols; c += 256) {
+      const float gm = load1(a.gamma, c, a.w_dtype) + (a.zero_centered ? 1.f : 0.f);
+      const float y = (load1(a.x, base + c, a.x_dtype) - mean) * rs;
+      const float dz = load1(a.dz, base + c, a.w_dtype);
+      const float dy = gm * dz;
+      pg[c] += y * dz;           // each column is owned by one thread of this workgroup
+      if constexpr (LN) {
+        pg[a.cols + c] += dz;
+        sdy += dy;
+      }
+      sdyy += dy * y;
+    }
+    block_sum2(sdy, sdyy, red, phase);
+    const float mdy = sdy * rn, mdyy = sdyy * rn;
+    for (unsigned c = tid; c < a.cols; c += 256) {
+      const float gm = load1(a.gamma, c, a.w_dtype) + (a.zero_centered ? 1.f : 0.f);
+      const float y = (load1(a.x, base + c, a.x_dtype) - mean) * rs;
+      const float dy = gm * load1(a.dz, base + c, a.w_dtype);
+      const float ad = a.add ? load1(a.add, base + c, a.w_dtype) : 0.f;
+      store1(a.dx, base + c, a.x_dtype, ad + rs * (dy - mdyy * y - mdy));
+    }
+  }
+}
+
+// dgamma[c] = sum over workgroups of part[b][0][c]; dbeta likewise from part[b][1][c]
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float *part, unsigned nblocks, unsigned cols,
+                                                                void *dgamma, void *dbeta, int w_dtype) {
+  const unsigned c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float sg = 0.f, sb = 0.f;
+  for (unsigned b = 0; b < nblocks; ++b) {
+    sg += part[static_cast<size_t>(b) * 2 * cols + c];
+    if (dbeta) sb += part[static_cast<size_t>(b) * 2 * cols + cols + c];
+  }
+  store1(dgamma, c, w_dtype, sg);
+  if (dbeta) store1(dbeta, c, w_dtype, sb);
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+unsigned norm_grid(size_t rows) {
+  const size_t want = static_cast<size_t>(device_info().num_cus) * 4;
+  return static_cast<unsigned>(std::max<size_t>(1, std::min(rows, want)));
+}
+
+bool shape_is_2d(const Buf &b) { return b.shape.ndim == 2; }
+
+template <bool LN>
+void launch_fwd(const NormFwdArgs &args, bool vec, hipStream_t stream) {
+  const dim3 grid(norm_grid(args.rows)), block(256);
+  if (!vec) {
+    hipLaunchKernelGGL(norm_fwd_general_kernel<LN>, grid, block, 0, stream, args);
+  } else if (args.cols <= 2048) {
+    hipLaunchKernelGGL((norm_fwd_kernel<1, LN>), grid, block, 0, stream, args);
+  } else if (args.cols <= 4096) {
+    hipLaunchKernelGGL((norm_fwd_kernel<2, LN>), grid, block, 0, stream, args);
+  } else if (args.cols <= 8192) {
+    hipLaunchKernelGGL((norm_fwd_kernel<4, LN>), grid, block, 0, stream, args);
+  } else {
+    hipLaunchKernelGGL((norm_fwd_kernel<8, LN>), grid, block, 0, stream, args);
+  }
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+template <bool LN>
+void launch_bwd(const NormBwdArgs &args, unsigned nblocks, bool vec, hipStream_t stream) {
+  const dim3 grid(nblocks), block(256);
+  if (!vec) {
+    hipLaunchKernelGGL(norm_bwd_general_kernel<LN>, grid, block, 0, stream, args);
+  } else if (args.cols <= 2048) {
+    hipLaunchKernelGGL((norm_bwd_kernel<1, LN>), grid, block, 0, stream, args);
+  } else if (args.cols <= 4096) {
+    hipLaunchKernelGGL((norm_bwd_kernel<2, LN>), grid, block, 0, stream, args);
+  } else {
+    hipLaunchKernelGGL((norm_bwd_kernel<4, LN>), grid, block, 0, stream, args);
+  }
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+// Forward entry shared by both norms (ref ln_api.cpp:24-110, rmsnorm_api.cpp:24-110).
+void norm_fwd(bool is_ln, const Tensor &x, const Tensor &gamma, const Tensor *beta, float epsilon, Tensor *z,
+              Tensor *mu, Tensor *rsigma, Tensor *workspace, bool zero_centered_gamma, hipStream_t stream) {
+  if (is_fp8(z->data.dtype) && !is_tensor_scaling(z->scaling_mode) && !is_mxfp8(z->scaling_mode)) {
+    NVTE_ERROR("Not implemented scaling mode: ", scaling_mode_name(z->scaling_mode), ".");
+  }
+  const bool mx = is_mxfp8(z->scaling_mode);
+  if (mx) {
+    NVTE_CHECK(!z->with_gemm_swizzled_scales, "MXFP8 output must have scales in compact format, not swizzled for GEMM.");
+  }
+  NVTE_CHECK(shape_is_2d(x.data), "x must be 2D tensor.");
+  const size_t rows = x.data.shape.data[0], cols = x.data.shape.data[1];
+  NVTE_CHECK(gamma.data.shape.data[0] == cols, "Gamma must have the same hidden size.");
+  if (is_ln) {
+    NVTE_CHECK(beta->data.shape.ndim == gamma.data.shape.ndim && beta->data.shape.data[0] == cols,
+               "Gamma and Beta must have the same shape.");
+    NVTE_CHECK(beta->data.dtype == gamma.data.dtype, "Gamma and Beta must have the same dtype.");
+  }
+  NVTE_CHECK(epsilon >= 0.f, "Epsilon must be non-negative.");
+  NVTE_CHECK(same_shape(z->data.shape, x.data.shape) ||
+                 (!z->has_data() && z->has_columnwise_data()),
+             "Output tensor must have the same shape as x.");
+  NVTE_CHECK(rsigma->data.shape.ndim == 1 && rsigma->data.shape.data[0] == rows,
+             "RSigma must be 1D tensor with shape (x.shape[0],).");
+  NVTE_CHECK(rsigma->data.dtype == kNVTEFloat32, "RSigma must be a float32 tensor.");
+  if (is_ln) {
+    NVTE_CHECK(mu->data.shape.ndim == 1 && mu->data.shape.data[0] == rows,
+               "Mu must be 1D tensor with shape (x.shape[0],).");
+    NVTE_CHECK(mu->data.dtype == kNVTEFloat32, "Mu must be a float32 tensor.");
+  }
+  NVTE_CHECK(is_high_precision(x.data.dtype) && is_high_precision(gamma.data.dtype),
+             "x and gamma must be FP32/BF16/FP16");
+  NVTE_CHECK(rows < (1ull << 32) && cols < (1ull << 31), "tensor too large");
+
+  // workspace: only MXFP8 output needs one (the normalized rows in the input dtype, quantized by the
+  // MXFP8 kernel afterwards); everything else reports a token size so that the two-call protocol
+  // of the reference keeps working
+  const size_t ws_bytes = mx ? rows * cols * dtype_bits(x.data.dtype) / 8 : 16;
+  if (workspace->data.numel() == 0) {
+    workspace->data.shape = nvte_make_shape(&ws_bytes, 1);
+    workspace->data.dtype = kNVTEByte;
+    return;
+  }
+  NVTE_CHECK(workspace->data.numel() * dtype_bits(workspace->data.dtype) / 8 >= ws_bytes && workspace->data.ptr,
+             "Workspace is too small (", ws_bytes, " bytes needed)");
+  check_input(x, "x");
+  check_input(gamma, "gamma");
+  check_output(*z, "z");
+  check_output(*rsigma, "rsigma");
+  if (rows == 0 || cols == 0) return;
+  (void)device_info();
+
+  NormFwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x.data.ptr;
+  a.gamma = gamma.data.ptr;
+  a.beta = is_ln ? beta->data.ptr : nullptr;
+  a.mu = is_ln ? static_cast<float *>(mu->data.ptr) : nullptr;
+  a.rs = static_cast<float *>(rsigma->data.ptr);
+  a.rows = static_cast<unsigned>(rows);
+  a.cols = static_cast<unsigned>(cols);
+  a.eps = epsilon;
+  a.x_dtype = x.data.dtype;
+  a.w_dtype = gamma.data.dtype;
+  a.zero_centered = zero_centered_gamma ? 1 : 0;
+  if (mx) {
+    a.z = workspace->data.ptr;
+    a.z_dtype = x.data.dtype;
+  } else {
+    NVTE_CHECK(z->has_data(), "Output z needs row-wise data");
+    a.z = z->data.ptr;
+    a.z_dtype = z->data.dtype;
+    if (is_fp8(z->data.dtype)) {
+      a.scale = static_cast<const float *>(z->scale.ptr);
+      a.scale_inv = static_cast<float *>(z->scale_inv.ptr);
+    }
+    a.amax = static_cast<float *>(z->amax.ptr);
+  }
+  const bool vec = cols % 8 == 0 && cols <= 16384 && aligned16(a.x) && aligned16(a.z) &&
+                   (cols * dtype_bits(static_cast<DType>(a.z_dtype)) / 8) % 8 == 0;
+  if (is_ln) launch_fwd<true>(a, vec, stream); else launch_fwd<false>(a, vec, stream);
+
+  if (mx) {
+    Tensor tmp;
+    tmp.reset(NVTE_DELAYED_TENSOR_SCALING);
+    tmp.data.ptr = workspace->data.ptr;
+    tmp.data.dtype = x.data.dtype;
+    tmp.data.shape = x.data.shape;
+    mxfp8_quantize_launch(tmp, nullptr, *z, stream);
+  } else if (z->has_columnwise_data() && is_tensor_scaling(z->scaling_mode) && is_fp8(z->data.dtype)) {
+    // FP8 transpose after the row kernel (ref rmsnorm_api.cpp:96-103)
+    Tensor row_only = *z, t_only;
+    row_only.columnwise_data.reset();
+    t_only.reset(z->scaling_mode);
+    t_only.data = z->columnwise_data;
+    transpose_launch(row_only, nullptr, t_only, stream);
+  }
+}
+
+void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, const Tensor &rsigma,
+              const Tensor &gamma, const Tensor *add, Tensor *dx, Tensor *dgamma, Tensor *dbeta, Tensor *workspace,
+              bool zero_centered_gamma, hipStream_t stream) {
+  NVTE_CHECK(dz.data.dtype == gamma.data.dtype, "dz and gamma must have the same dtype");
+  NVTE_CHECK(rsigma.data.dtype == kNVTEFloat32, "rsigma must be a float32 tensor");
+  NVTE_CHECK(shape_is_2d(x.data), "x must be 2D tensor.");
+  NVTE_CHECK(same_shape(dz.data.shape, x.data.shape), "dz must have the same shape as x");
+  const size_t rows = x.data.shape.data[0], cols = x.data.shape.data[1];
+  NVTE_CHECK(gamma.data.shape.data[0] == cols, "Gamma must have the same hidden size.");
+  NVTE_CHECK(same_shape(dx->data.shape, x.data.shape) && dx->data.dtype == x.data.dtype,
+             "dx must have the shape and dtype of x");
+  NVTE_CHECK(same_shape(dgamma->data.shape, gamma.data.shape) && dgamma->data.dtype == gamma.data.dtype,
+             "dgamma must have the shape and dtype of gamma");
+  if (is_ln) {
+    NVTE_CHECK(mu->data.dtype == kNVTEFloat32, "mu must be a float32 tensor");
+    NVTE_CHECK(same_shape(dbeta->data.shape, gamma.data.shape) && dbeta->data.dtype == gamma.data.dtype,
+               "dbeta must have the shape and dtype of gamma");
+  }
+  if (add) {
+    NVTE_CHECK(same_shape(add->data.shape, x.data.shape) && add->data.dtype == gamma.data.dtype,
+               "add must have the shape of x and the dtype of gamma");
+  }
+  NVTE_CHECK(is_high_precision(x.data.dtype) && is_high_precision(gamma.data.dtype),
+             "x and gamma must be FP32/BF16/FP16");
+  const unsigned nblocks = norm_grid(rows);
+  const size_t ws_bytes = static_cast<size_t>(nblocks) * 2 * cols * sizeof(float);
+  if (workspace->data.numel() == 0) {
+    workspace->data.shape = nvte_make_shape(&ws_bytes, 1);
+    workspace->data.dtype = kNVTEByte;
+    return;
+  }
+  NVTE_CHECK(workspace->data.numel() * dtype_bits(workspace->data.dtype) / 8 >= ws_bytes && workspace->data.ptr,
+             "Workspace is too small (", ws_bytes, " bytes needed)");
+  NVTE_CHECK(aligned16(workspace->data.ptr), "Workspace must be 16-byte aligned");
+  if (rows == 0 || cols == 0) return;
+  (void)device_info();
+  NormBwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.dz = dz.data.ptr;
+  a.x = x.data.ptr;
+  a.gamma = gamma.data.ptr;
+  a.add = add ? add->data.ptr : nullptr;
+  a.mu = is_ln ? static_cast<const float *>(mu->data.ptr) : nullptr;
+  a.rs = static_cast<const float *>(rsigma.data.ptr);
+  a.dx = dx->data.ptr;
+  a.part = static_cast<float *>(workspace->data.ptr);
+  a.rows = static_cast<unsigned>(rows);
+  a.cols = static_cast<unsigned>(cols);
+  a.x_dtype = x.data.dtype;
+  a.w_dtype = gamma.data.dtype;
+  a.zero_centered = zero_centered_gamma ? 1 : 0;
+  const bool vec = cols % 8 == 0 && cols <= 8192 && aligned16(a.x) && aligned16(a.dz) && aligned16(a.dx) &&
+                   (!a.add || aligned16(a.add));
+  if (is_ln) launch_bwd<true>(a, nblocks, vec, stream); else launch_bwd<false>(a, nblocks, vec, stream);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 256))), dim3(256), 0, stream,
+                     a.part, nblocks, a.cols, dgamma->data.ptr, is_ln ? dbeta->data.ptr : nullptr, a.w_dtype);
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace
+}  // namespace te
+
+using namespace te;
+
+extern "C" {
+
+void nvte_layernorm_fwd(const NVTETensor x, const NVTETensor gamma, const NVTETensor beta, const float epsilon,
+                        NVTETensor z, NVTETensor mu, NVTETensor rsigma, NVTETensor workspace,
+                        const int multiprocessorCount, const bool zero_centered_gamma, hipStream_t stream) {
+  api_guard("nvte_layernorm_fwd", [&] {
+    (void)multiprocessorCount;
+    norm_fwd(true, *lookup_checked(x), *lookup_checked(gamma), lookup_checked(beta), epsilon, lookup_checked(z),
+             lookup_checked(mu), lookup_checked(rsigma), lookup_checked(workspace), zero_centered_gamma, stream);
+  });
+}
+
+void nvte_rmsnorm_fwd(const NVTETensor x, const NVTETensor gamma, const float epsilon, NVTETensor z,
+                      NVTETensor rsigma, NVTETensor workspace, const int multiprocessorCount,
+                      const bool zero_centered_gamma, hipStream_t stream) {
+  api_guard("nvte_rmsnorm_fwd", [&] {
+    (void)multiprocessorCount;
+    norm_fwd(false, *lookup_checked(x), *lookup_checked(gamma), nullptr, epsilon, lookup_checked(z), nullptr,
+             lookup_checked(rsigma), lookup_checked(workspace), zero_centered_gamma, stream);
+  });
+}
+
+void nvte_layernorm_bwd(const NVTETensor dz, const NVTETensor x, const NVTETensor mu, const NVTETensor rsigma,
+                        const NVTETensor gamma, NVTETensor dx, NVTETensor dgamma, NVTETensor dbeta,
+                        NVTETensor workspace, const int multiprocessorCount, const bool zero_centered_gamma,
+                        hipStream_t stream) {
+  api_guard("nvte_layernorm_bwd", [&] {
+    (void)multiprocessorCount;
+    norm_bwd(true, *lookup_checked(dz), *lookup_checked(x), lookup_checked(mu), *lookup_checked(rsigma),
+             *lookup_checked(gamma), nullptr, lookup_checked(dx), lookup_checked(dgamma), lookup_checked(dbeta),
+             lookup_checked(workspace), zero_centered_gamma, stream);
+  });
+}
+
+void nvte_rmsnorm_bwd(const NVTETensor dz, const NVTETensor x, const NVTETensor rsigma, const NVTETensor gamma,
+                      NVTETensor dx, NVTETensor dgamma, NVTETensor workspace, const int multiprocessorCount,
+                      const bool zero_centered_gamma, hipStream_t stream) {
+  api_guard("nvte_rmsnorm_bwd", [&] {
+    (void)multiprocessorCount;
+    norm_bwd(false, *lookup_checked(dz), *lookup_checked(x), nullptr, *lookup_checked(rsigma), *lookup_checked(gamma),
+             nullptr, lookup_checked(dx), lookup_checked(dgamma), nullptr, lookup_checked(workspace),
+             zero_centered_gamma, stream);
+  });
+}
+
+void nvte_rmsnorm_bwd_add(const NVTETensor dz, const NVTETensor x, const NVTETensor add, const NVTETensor rsigma,
+                          const NVTETensor gamma, NVTETensor dx, NVTETensor dgamma, NVTETensor workspace,
+                          const int multiprocessorCount, const bool zero_centered_gamma, hipStream_t stream) {
+  api_guard("nvte_rmsnorm_bwd_add", [&] {
+    (void)multiprocessorCount;
+    norm_bwd(false, *lookup_checked(dz), *lookup_checked(x), nullptr, *lookup_checked(rsigma), *lookup_checked(gamma),
+             lookup_checked(add), lookup_checked(dx), lookup_checked(dgamma), nullptr, lookup_checked(workspace),
+             zero_centered_gamma, stream);
+  });
+}
+
+void nvte_enable_cudnn_norm_fwd(bool) {}
+void nvte_enable_cudnn_norm_bwd(bool) {}
+void nvte_enable_zero_centered_gamma_in_weight_dtype(bool) {}
+
+}  // extern "C"
