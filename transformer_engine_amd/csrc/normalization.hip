@@ -394,23 +394,36 @@ __global__ __launch_bounds__(256) void norm_bwd_general_kernel(const NormBwdArgs
 }
 
 // dgamma[c] = sum over workgroups of part[b][0][c]; dbeta likewise from part[b][1][c]
+// One workgroup per 64 columns: wave w sums the partials of workgroups w, w + 4, ... (a wave reads 256
+// contiguous bytes per partial row, four rows in flight), the 4 waves meet in LDS.
 __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float *part, unsigned nblocks, unsigned cols,
                                                                 void *dgamma, void *dbeta, int w_dtype) {
-  const unsigned c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float acc[2][4][64];
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const unsigned c = blockIdx.x * 64 + lane;
   float sg = 0.f, sb = 0.f;
-  for (unsigned b = 0; b < nblocks; ++b) {
-    sg += part[static_cast<size_t>(b) * 2 * cols + c];
-    if (dbeta) sb += part[static_cast<size_t>(b) * 2 * cols + cols + c];
+  if (c < cols) {
+#pragma unroll 4
+    for (unsigned b = w; b < nblocks; b += 4) {
+      sg += part[static_cast<size_t>(b) * 2 * cols + c];
+      if (dbeta) sb += part[static_cast<size_t>(b) * 2 * cols + cols + c];
+    }
   }
-  store1(dgamma, c, w_dtype, sg);
-  if (dbeta) store1(dbeta, c, w_dtype, sb);
+  acc[0][w][lane] = sg;
+  acc[1][w][lane] = sb;
+  __syncthreads();
+  if (w == 0 && c < cols) {
+    store1(dgamma, c, w_dtype, acc[0][0][lane] + acc[0][1][lane] + acc[0][2][lane] + acc[0][3][lane]);
+    if (dbeta) store1(dbeta, c, w_dtype, acc[1][0][lane] + acc[1][1][lane] + acc[1][2][lane] + acc[1][3][lane]);
+  }
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-unsigned norm_grid(size_t rows) {
-  const size_t want = static_cast<size_t>(device_info().num_cus) * 4;
+// Persistent workgroups: as many per CU as the kernel's register use lets run at once
+// (forward: 46-56 / 70-76 / 121-128 / 225-232 VGPRs for 1 / 2 / 4 / 8 vectors per thread).
+unsigned norm_grid(size_t rows, unsigned per_cu) {
+  const size_t want = static_cast<size_t>(device_info().num_cus) * per_cu;
   return static_cast<unsigned>(std::max<size_t>(1, std::min(rows, want)));
 }
 
@@ -418,7 +431,8 @@ bool shape_is_2d(const Buf &b) { return b.shape.ndim == 2; }
 
 template <bool LN>
 void launch_fwd(const NormFwdArgs &args, bool vec, hipStream_t stream) {
-  const dim3 grid(norm_grid(args.rows)), block(256);
+  const unsigned per_cu = !vec ? 8 : args.cols <= 2048 ? 8 : args.cols <= 4096 ? 6 : args.cols <= 8192 ? 4 : 2;
+  const dim3 grid(norm_grid(args.rows, per_cu)), block(256);
   if (!vec) {
     hipLaunchKernelGGL(norm_fwd_general_kernel<LN>, grid, block, 0, stream, args);
   } else if (args.cols <= 2048) {
@@ -571,7 +585,8 @@ void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, c
   }
   NVTE_CHECK(is_high_precision(x.data.dtype) && is_high_precision(gamma.data.dtype),
              "x and gamma must be FP32/BF16/FP16");
-  const unsigned nblocks = norm_grid(rows);
+  // one or two workgroups per CU: the partial dgamma / dbeta rows they leave behind are re-read
+  const unsigned nblocks = norm_grid(rows, cols <= 4096 ? 2 : 1);
   const size_t ws_bytes = static_cast<size_t>(nblocks) * 2 * cols * sizeof(float);
   if (workspace->data.numel() == 0) {
     workspace->data.shape = nvte_make_shape(&ws_bytes, 1);
@@ -601,7 +616,7 @@ void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, c
   const bool vec = cols % 8 == 0 && cols <= 8192 && aligned16(a.x) && aligned16(a.dz) && aligned16(a.dx) &&
                    (!a.add || aligned16(a.add));
   if (is_ln) launch_bwd<true>(a, nblocks, vec, stream); else launch_bwd<false>(a, nblocks, vec, stream);
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 256))), dim3(256), 0, stream,
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 64))), dim3(256), 0, stream,
                      a.part, nblocks, a.cols, dgamma->data.ptr, is_ln ? dbeta->data.ptr : nullptr, a.w_dtype);
   NVTE_CHECK_HIP(hipGetLastError());
 }
