@@ -153,6 +153,53 @@ def linear_backward(dy: torch.Tensor, saved, st: LinearFP8State, *, use_bias: bo
     return dx, dw, dbias
 
 
+def layernorm_linear_forward(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: Optional[torch.Tensor],
+                             weight: torch.Tensor, bias: Optional[torch.Tensor], st: LinearFP8State, *,
+                             eps: float = 1e-5, normalization: str = "LayerNorm", zero_centered_gamma: bool = False,
+                             is_first_microbatch: Optional[bool] = None, needs_backward: bool = True):
+    """``LayerNormLinear`` forward (ref pytorch/module/layernorm_linear.py:180-420): the norm writes the
+    GEMM's FP8 input directly (delayed scaling / MXFP8: fused in the norm kernel; current scaling:
+    norm to high precision, then amax -> scale -> cast), so the normalized activation never makes a
+    bf16 round trip through HBM.  Returns (y, saved)."""
+    from .normalization import layernorm_fwd, rmsnorm_fwd
+    qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
+    qi.set_usage(rowwise=True, columnwise=needs_backward)
+    x2d = x.reshape(-1, x.shape[-1])
+    if normalization == "LayerNorm":
+        ln8, mu, rsigma = layernorm_fwd(x2d, ln_weight, ln_bias, eps, quantizer=qi,
+                                        zero_centered_gamma=zero_centered_gamma)
+    elif normalization == "RMSNorm":
+        ln8, mu, rsigma = rmsnorm_fwd(x2d, ln_weight, eps, quantizer=qi, zero_centered_gamma=zero_centered_gamma)
+    else:
+        raise ValueError(f"unsupported normalization {normalization}")
+    if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
+        qw.set_usage(rowwise=True, columnwise=needs_backward)
+        w8 = qw(weight)
+        if is_first_microbatch is not None:
+            st.weight_cache = w8
+    else:
+        w8 = st.weight_cache
+    y, *_ = general_gemm(w8, ln8, out_dtype=x.dtype, layout="TN", bias=bias)
+    return y.reshape(*x.shape[:-1], weight.shape[0]), (ln8, w8, x2d, mu, rsigma)
+
+
+def layernorm_linear_backward(dy: torch.Tensor, saved, ln_weight: torch.Tensor, st: LinearFP8State, *,
+                              normalization: str = "LayerNorm", zero_centered_gamma: bool = False,
+                              use_bias: bool = False):
+    """Returns (dx, dgamma, dbeta or None, dw, dbias): Linear backward, then the norm backward on dgrad
+    (ref layernorm_linear.py:560-1010)."""
+    from .normalization import layernorm_bwd, rmsnorm_bwd
+    ln8, w8, x2d, mu, rsigma = saved
+    dln, dw, dbias = linear_backward(dy, (ln8, w8), st, use_bias=use_bias, grad_dtype=ln_weight.dtype)
+    dln = dln.reshape(x2d.shape)
+    if normalization == "LayerNorm":
+        dx, dgamma, dbeta = layernorm_bwd(dln, x2d, mu, rsigma, ln_weight, zero_centered_gamma=zero_centered_gamma)
+    else:
+        dx, dgamma = rmsnorm_bwd(dln, x2d, rsigma, ln_weight, zero_centered_gamma=zero_centered_gamma)
+        dbeta = None
+    return dx, dgamma, dbeta, dw, dbias
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, module):
