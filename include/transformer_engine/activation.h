@@ -1,0 +1,49 @@
+/* Activations fused with the cast to FP8: the step either side of a
+ * Linear in an MLP (FC1 -> act -> FC2).  Mirrors ref common/include/transformer_engine/activation.h;
+ * the math is ref common/util/math.h:21-134, the gated layout ref util/vectorized_pointwise.h:410-560
+ * (input [N, 2H]: activation half first, gate half second).
+ *
+ * Every OUTPUT may be FP32/BF16/FP16 (row-wise) or FP8 with per-tensor scaling: scale in,
+ * amax (of the pre-scale value) and scale_inv out, and - when the output carries a column-wise
+ * buffer - the transpose written by the same kernel.  MXFP8 outputs are not implemented here. */
+#ifndef TE_AMD_ACTIVATION_H_
+#define TE_AMD_ACTIVATION_H_
+
+#include "transformer_engine.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ref activation.h:54-138: output = act(input) */
+void nvte_gelu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_silu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_relu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_qgelu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_srelu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+/* ref activation.h:160-260: output = grad * act'(input) */
+void nvte_dgelu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dsilu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_drelu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dqgelu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dsrelu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+/* ref activation.h:288-439: input [N, 2H] -> output [N, H] = act(input[:, :H]) * input[:, H:] */
+void nvte_glu(const NVTETensor input, NVTETensor output, hipStream_t stream);     /* sigmoid gate */
+void nvte_geglu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_swiglu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_reglu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_qgeglu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_sreglu(const NVTETensor input, NVTETensor output, hipStream_t stream);
+/* ref activation.h:299,450-587: grad [N, H], input [N, 2H] -> output [N, 2H] =
+ * [ act'(a) * grad * b , act(a) * grad ] */
+void nvte_dglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dgeglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dswiglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dreglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dqgeglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+void nvte_dsreglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

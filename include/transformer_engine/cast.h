@@ -43,6 +43,19 @@ void nvte_group_quantize(const NVTEGroupedTensor input, NVTEGroupedTensor output
 /* ref cast.h:429 */
 void nvte_group_dequantize(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
 
+/* ref cast.h:190-384.  output = cast(input * act'(act_input)), dbias[c] = sum_r of that product (in the
+ * input dtype), ONE pass over the data.  Two-call workspace protocol as nvte_quantize_dbias. */
+void nvte_quantize_dbias_dgelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                               NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_quantize_dbias_dsilu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                               NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_quantize_dbias_drelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                               NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_quantize_dbias_dqgelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_quantize_dbias_dsrelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

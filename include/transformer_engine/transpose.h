@@ -23,6 +23,30 @@ void nvte_cast_transpose_dbias(const NVTETensor input, NVTETensor output, NVTETe
 void nvte_multi_cast_transpose(size_t num_tensors, const NVTETensor *input_list,
                                NVTETensor *output_list, hipStream_t stream);
 
+/* ref transpose.h:118-222: the older names of nvte_quantize_dbias_d<act> for outputs that carry both
+ * layouts (cast + transpose + dbias of input * act'(act_input) in one pass). */
+void nvte_cast_transpose_dbias_dgelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                     NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_cast_transpose_dbias_dsilu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                     NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_cast_transpose_dbias_drelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                     NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_cast_transpose_dbias_dqgelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                      NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+void nvte_cast_transpose_dbias_dsrelu(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                      NVTETensor dbias, NVTETensor workspace, hipStream_t stream);
+/* ref transpose.h:242-318: gated backward (see activation.h) with cast + transpose of the [N, 2H] result */
+void nvte_dgeglu_cast_transpose(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                hipStream_t stream);
+void nvte_dswiglu_cast_transpose(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                 hipStream_t stream);
+void nvte_dreglu_cast_transpose(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                hipStream_t stream);
+void nvte_dqgeglu_cast_transpose(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                 hipStream_t stream);
+void nvte_dsreglu_cast_transpose(const NVTETensor input, const NVTETensor act_input, NVTETensor output,
+                                 hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

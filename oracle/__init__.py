@@ -103,6 +103,9 @@ def lib() -> ctypes.CDLL:
         L.te_norm_backward_ref.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int,
                                            c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                            c.c_size_t, c.c_size_t, c.c_int]
+        L.te_act_ref.restype = None
+        L.te_act_ref.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t,
+                                 c.c_size_t]
         L.te_colsum_ref.restype = None
         L.te_colsum_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_void_p]
         L.te_oracle_num_threads.restype = c.c_int
@@ -311,6 +314,23 @@ def norm_backward(dz: np.ndarray, x: np.ndarray, mu, rsigma: np.ndarray, gamma: 
                                _in_dtype(x), _in_dtype(gamma), _ptr(mu_c) if is_ln else None, _ptr(rs_c), _ptr(gamma),
                                _ptr(dx), _ptr(dg), _ptr(db) if is_ln else None, N, H, int(zero_centered_gamma))
     return dx, dg, db
+
+
+ACT_IDS = {"none": 0, "gelu": 1, "silu": 2, "relu": 3, "qgelu": 4, "srelu": 5, "sigmoid": 6}
+ACT_MODES = {"unary": 0, "dact": 1, "gated": 2, "dgated": 3}
+
+
+def activation(mode: str, act: str, x: np.ndarray, grad=None) -> np.ndarray:
+    """fp32 result of act / grad*act' / gated forward / gated backward (ref common/util/math.h,
+    util/vectorized_pointwise.h:410-560); x is [R, H] or, for the gated modes, [R, 2H]."""
+    x = np.ascontiguousarray(x)
+    R = x.shape[0]
+    H = x.shape[1] // 2 if mode in ("gated", "dgated") else x.shape[1]
+    out = np.empty((R, 2 * H if mode == "dgated" else H), np.float32)
+    g = np.ascontiguousarray(grad) if grad is not None else None
+    lib().te_act_ref(ACT_MODES[mode], ACT_IDS[act], _ptr(x), _ptr(g) if g is not None else None, _in_dtype(x),
+                     _ptr(out), R, H)
+    return out
 
 
 def colsum(x: np.ndarray) -> np.ndarray:

@@ -504,6 +504,48 @@ void te_norm_backward_ref(int is_ln, const void *dz, const void *add, const void
   }
 }
 
+/* ------------------------------------------------------------------ activations
+ * ref common/util/math.h:21-134.  id: 1 gelu, 2 silu, 3 relu, 4 qgelu, 5 srelu, 6 sigmoid (the "act"
+ * of plain GLU); deriv != 0 returns the derivative. */
+static inline float sigmoid_ref(float x) { return 1.f / (1.f + expf(-x)); }
+float te_act_scalar_ref(int id, int deriv, float x) {
+  switch (id) {
+    case 1:
+      if (!deriv) return x * (0.5f + 0.5f * tanhf(x * (0.79788456f + 0.03567741f * x * x)));
+      else {
+        const float t = tanhf(0.79788456f * x * (1.f + 0.044715f * x * x));
+        return 0.5f * x * ((1.f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.f + t);
+      }
+    case 2: { const float s = sigmoid_ref(x); return deriv ? x * (s * (1.f - s)) + s : x * s; }
+    case 3: return deriv ? (x > 0.f ? 1.f : 0.f) : fmaxf(x, 0.f);
+    case 4: { const float s = sigmoid_ref(1.702f * x);
+              return deriv ? 1.702f * x * (s * (1.f - s)) + s : x * s; }
+    case 5: return deriv ? fmaxf(2.f * x, 0.f) : (x > 0.f ? x * x : 0.f);
+    case 6: { const float s = sigmoid_ref(x); return deriv ? s * (1.f - s) : s; }
+    default: return deriv ? 1.f : x;
+  }
+}
+
+/* mode 0: out[r,c] = act(in[r,c]); 1: grad*act'(in); 2 (gated fwd, in [R,2H]): act(a)*b;
+ * 3 (gated bwd, out [R,2H]): [act'(a)*grad*b, act(a)*grad]   (ref util/vectorized_pointwise.h:410-560).
+ * fp32 results before any output conversion. */
+void te_act_ref(int mode, int id, const void *in, const void *grad, int dtype, float *out, size_t R, size_t H) {
+  const size_t ld_in = (mode >= 2) ? 2 * H : H, ld_out = (mode == 3) ? 2 * H : H;
+  for (size_t r = 0; r < R; ++r)
+    for (size_t c = 0; c < H; ++c) {
+      const float a = load_in(in, r * ld_in + c, dtype);
+      const float b = (mode >= 2) ? load_in(in, r * ld_in + H + c, dtype) : 0.f;
+      const float g = (mode == 1 || mode == 3) ? load_in(grad, r * H + c, dtype) : 0.f;
+      if (mode == 0) out[r * ld_out + c] = te_act_scalar_ref(id, 0, a);
+      else if (mode == 1) out[r * ld_out + c] = g * te_act_scalar_ref(id, 1, a);
+      else if (mode == 2) out[r * ld_out + c] = te_act_scalar_ref(id, 0, a) * b;
+      else {
+        out[r * ld_out + c] = te_act_scalar_ref(id, 1, a) * g * b;
+        out[r * ld_out + H + c] = g * te_act_scalar_ref(id, 0, a);
+      }
+    }
+}
+
 int te_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

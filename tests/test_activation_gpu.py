@@ -1,0 +1,131 @@
+"""GPU parity of the fused activation kernels (plain / gated, forward / backward, + cast + transpose + dbias).
+
+Oracle: C restatement of ref common/util/math.h and of the gated layout of util/vectorized_pointwise.h.
+Floating point: device expf/tanhf vs glibc's differ in the last bits, so high-precision outputs are
+compared with the tolerance of the reference's activation tests (tests/cpp/operator/test_act.cu uses
+getTolerances(otype): fp32 1e-6/5e-6 ... bf16 1e-5/1e-2), FP8 bytes must match the oracle's codes except
+at fp32 rounding boundaries (<= one code step, on < 0.5 % of the elements); amax / scale_inv / dbias with
+fp32 tolerances; transposes are byte-exact transposes of the row-wise payload.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import FMT, randn_input, to_oracle_input, u8
+from transformer_engine_amd.activation import GATED, UNARY, activation, dactivation, dbias_dact
+from transformer_engine_amd.tensor import DType, Float8CurrentScalingQuantizer, Float8Quantizer
+
+pytestmark = pytest.mark.gpu
+E4, E5 = DType.kFloat8E4M3, DType.kFloat8E5M2
+ORACLE_ACT = {"gelu": "gelu", "silu": "silu", "relu": "relu", "qgelu": "qgelu", "srelu": "srelu",
+              "glu": "sigmoid", "geglu": "gelu", "swiglu": "silu", "reglu": "relu", "qgeglu": "qgelu", "sreglu": "srelu"}
+
+
+def _ref(name, x, grad=None):
+    gated = name in GATED
+    mode = ("dgated" if gated else "dact") if grad is not None else ("gated" if gated else "unary")
+    return oracle.activation(mode, ORACLE_ACT[name], to_oracle_input(x), to_oracle_input(grad) if grad is not None else None)
+
+
+def _check_fp8(out, ref, scale, fmt, amax):
+    got = oracle.fp8_to_float(u8(out._data), FMT[fmt])
+    want = oracle.fp8_to_float(oracle.float_to_fp8(ref * np.float32(scale), FMT[fmt]), FMT[fmt])
+    step = 2.0 ** -3 if fmt == E4 else 2.0 ** -2
+    sub = 2.0 ** -9 if fmt == E4 else 2.0 ** -16
+    diff = np.abs(got - want)
+    assert (diff <= step * np.abs(want) + sub).all()
+    assert (diff != 0).mean() < 5e-3
+    assert np.isclose(amax, np.abs(ref).max(), rtol=1e-5)
+    assert out._scale_inv.item() == np.float32(1.0) / np.float32(scale)
+    if out._transpose is not None:
+        assert np.array_equal(u8(out._transpose), u8(out._data).T)
+
+
+@pytest.mark.parametrize("name", UNARY + GATED)
+@pytest.mark.parametrize("N,H", [(256, 512), (300, 264), (37, 100)])      # tiles / guarded tiles / element path
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_activation_forward_high_precision(name, N, H, dtype):
+    x = randn_input((N, 2 * H if name in GATED else H), dtype, 3) * 2
+    y = activation(name, x)
+    torch.cuda.synchronize()
+    ref = _ref(name, x)
+    tol = dict(rtol=5e-6, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-5)
+    assert y.shape == ref.shape
+    assert np.allclose(y.float().cpu().numpy(), ref, **tol)
+
+
+@pytest.mark.parametrize("name", UNARY + GATED)
+@pytest.mark.parametrize("N,H", [(256, 512), (304, 264), (37, 100)])
+def test_activation_backward_high_precision(name, N, H):
+    x = randn_input((N, 2 * H if name in GATED else H), torch.bfloat16, 4) * 2
+    g = randn_input((N, H), torch.bfloat16, 5)
+    dx = dactivation(name, g, x)
+    torch.cuda.synchronize()
+    ref = _ref(name, x, g)
+    assert dx.shape == ref.shape
+    assert np.allclose(dx.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["gelu", "swiglu", "srelu", "geglu"])
+@pytest.mark.parametrize("fmt", [E4, E5])
+@pytest.mark.parametrize("N,H", [(256, 512), (304, 264), (37, 100)])
+def test_activation_forward_fp8_cast_transpose(name, fmt, N, H):
+    x = randn_input((N, 2 * H if name in GATED else H), torch.bfloat16, 6) * 2
+    scale, amax = torch.full((1,), 5.5, device="cuda"), torch.zeros(1, device="cuda")
+    out = activation(name, x, Float8Quantizer(scale, amax, fmt))
+    torch.cuda.synchronize()
+    _check_fp8(out, _ref(name, x), 5.5, fmt, amax.item())
+
+
+@pytest.mark.parametrize("name", ["gelu", "silu", "swiglu", "reglu", "qgeglu"])
+@pytest.mark.parametrize("N,H", [(256, 512), (304, 264), (37, 100)])
+def test_activation_backward_fp8_cast_transpose(name, N, H):
+    x = randn_input((N, 2 * H if name in GATED else H), torch.bfloat16, 7) * 2
+    g = randn_input((N, H), torch.bfloat16, 8)
+    scale, amax = torch.full((1,), 3.0, device="cuda"), torch.zeros(1, device="cuda")
+    out = dactivation(name, g, x, Float8Quantizer(scale, amax, E5))
+    torch.cuda.synchronize()
+    _check_fp8(out, _ref(name, x, g), 3.0, E5, amax.item())
+
+
+@pytest.mark.parametrize("name", UNARY)
+@pytest.mark.parametrize("N,H", [(512, 768), (304, 264), (37, 100), (1000, 128)])
+def test_dbias_dact_fused(name, N, H):
+    x = randn_input((N, H), torch.bfloat16, 9) * 2
+    g = randn_input((N, H), torch.bfloat16, 10)
+    scale, amax = torch.full((1,), 2.0, device="cuda"), torch.zeros(1, device="cuda")
+    dbias, out = dbias_dact(name, g, x, Float8Quantizer(scale, amax, E5))
+    torch.cuda.synchronize()
+    ref = _ref(name, x, g)
+    _check_fp8(out, ref, 2.0, E5, amax.item())
+    want = ref.astype(np.float64).sum(axis=0)
+    # fp32 partial sums per 128-row slab, one bf16 rounding of the result
+    assert np.allclose(dbias.float().cpu().numpy(), want, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).sum(axis=0).max())
+
+
+def test_quantize_dbias_uses_the_fused_pass_and_matches_oracle_bytes():
+    """nvte_quantize_dbias for FP8 per-tensor scaling: bytes bit-exact as nvte_quantize, dbias = column sums."""
+    from transformer_engine_amd.linear import bgrad_quantize
+    for (N, H) in [(512, 768), (304, 264), (37, 100)]:
+        dy = randn_input((N, H), torch.bfloat16, 11)
+        scale, amax = torch.full((1,), 7.0, device="cuda"), torch.zeros(1, device="cuda")
+        dbias, out = bgrad_quantize(dy, Float8Quantizer(scale, amax, E5))
+        torch.cuda.synchronize()
+        rc, rt, ra, rs = oracle.cast_transpose(to_oracle_input(dy), 7.0, oracle.E5M2)
+        assert np.array_equal(u8(out._data), rc) and np.array_equal(u8(out._transpose), rt)
+        assert amax.item() == ra and out._scale_inv.item() == rs
+        ref = oracle.colsum(to_oracle_input(dy))
+        assert np.allclose(dbias.float().cpu().numpy(), ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(dy.float().cpu().numpy()).sum(axis=0).max())
+
+
+def test_activation_current_scaling_unfuses_and_mxfp8_is_rejected():
+    from transformer_engine_amd.tensor import MXFP8Quantizer
+    x = randn_input((128, 256), torch.bfloat16, 12)
+    q = Float8CurrentScalingQuantizer(E4, torch.device("cuda"))
+    out = activation("gelu", x, q)
+    ref = q(activation("gelu", x))
+    torch.cuda.synchronize()
+    assert torch.equal(out._data, ref._data) and torch.equal(out._scale_inv, ref._scale_inv)
+    with pytest.raises(NotImplementedError):
+        activation("gelu", x, MXFP8Quantizer(E4))

@@ -186,6 +186,44 @@ _SIGS = {
     "nvte_enable_cudnn_norm_fwd": (_V, [_B]),
     "nvte_enable_cudnn_norm_bwd": (_V, [_B]),
     "nvte_enable_zero_centered_gamma_in_weight_dtype": (_V, [_B]),
+    # activation.h + fused d-act entry points of cast.h / transpose.h
+    "nvte_gelu": (_V, [_P, _P, _P]),
+    "nvte_silu": (_V, [_P, _P, _P]),
+    "nvte_relu": (_V, [_P, _P, _P]),
+    "nvte_qgelu": (_V, [_P, _P, _P]),
+    "nvte_srelu": (_V, [_P, _P, _P]),
+    "nvte_glu": (_V, [_P, _P, _P]),
+    "nvte_geglu": (_V, [_P, _P, _P]),
+    "nvte_swiglu": (_V, [_P, _P, _P]),
+    "nvte_reglu": (_V, [_P, _P, _P]),
+    "nvte_qgeglu": (_V, [_P, _P, _P]),
+    "nvte_sreglu": (_V, [_P, _P, _P]),
+    "nvte_dgelu": (_V, [_P, _P, _P, _P]),
+    "nvte_dsilu": (_V, [_P, _P, _P, _P]),
+    "nvte_drelu": (_V, [_P, _P, _P, _P]),
+    "nvte_dqgelu": (_V, [_P, _P, _P, _P]),
+    "nvte_dsrelu": (_V, [_P, _P, _P, _P]),
+    "nvte_dglu": (_V, [_P, _P, _P, _P]),
+    "nvte_dgeglu": (_V, [_P, _P, _P, _P]),
+    "nvte_dswiglu": (_V, [_P, _P, _P, _P]),
+    "nvte_dreglu": (_V, [_P, _P, _P, _P]),
+    "nvte_dqgeglu": (_V, [_P, _P, _P, _P]),
+    "nvte_dsreglu": (_V, [_P, _P, _P, _P]),
+    "nvte_dgeglu_cast_transpose": (_V, [_P, _P, _P, _P]),
+    "nvte_dswiglu_cast_transpose": (_V, [_P, _P, _P, _P]),
+    "nvte_dreglu_cast_transpose": (_V, [_P, _P, _P, _P]),
+    "nvte_dqgeglu_cast_transpose": (_V, [_P, _P, _P, _P]),
+    "nvte_dsreglu_cast_transpose": (_V, [_P, _P, _P, _P]),
+    "nvte_quantize_dbias_dgelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_quantize_dbias_dsilu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_quantize_dbias_drelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_quantize_dbias_dqgelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_quantize_dbias_dsrelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_cast_transpose_dbias_dgelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_cast_transpose_dbias_dsilu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_cast_transpose_dbias_drelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_cast_transpose_dbias_dqgelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_cast_transpose_dbias_dsrelu": (_V, [_P, _P, _P, _P, _P, _P]),
     # swizzle.h
     "nvte_swizzle_scaling_factors": (_V, [_P, _P, _P]),
     "nvte_multi_tensor_swizzle_scaling_factors": (_V, [C.POINTER(_P), C.POINTER(_P), _SZ, _P]),

@@ -1,0 +1,435 @@
+// Activations (plain and gated, forward and backward) fused with the FP8 cast, the transpose and
+// the bias-gradient reduction: one pass over the data for what the unfused sequence does in three.
+//
+// Replaces (behaviour, not structure):
+//   ref common/activation/{gelu,relu,swiglu}.cu + activation_template.h (entry points),
+//       common/util/math.h:21-134 (the functions), util/vectorized_pointwise.h:176-227 (unary),
+//       :410-560 (gated forward / backward: input [N, 2H], activation half first),
+//       common/cast/cast_dbias*.cu, transpose/cast_transpose_fusion.cu:1260-1420
+//       (nvte_quantize_dbias_d<act>, nvte_cast_transpose_dbias_d<act>, nvte_d<gated>_cast_transpose).
+//
+// HBM-bound.  Algorithmic bytes per output element (bf16 in, FP8 out with transpose): unary 2+2,
+// d-act 4+2, gated forward 4+2, gated backward 3+2 per OUTPUT element.
+// Kernel: the 128x128 tile of cast_transpose.hip (8x8 values per thread, 16-byte loads, row-wise
+// bytes straight from registers, transposes through the XOR-swizzled LDS image), with the value
+// produced by a functor of up to three inputs; the dbias partial of a tile (sum over its 128 rows)
+// goes through 8 KiB of LDS into the [ceil(R/128), C] fp32 workspace of the existing two-call
+// protocol.  The activation is a wave-uniform runtime switch (free next to the memory traffic),
+// the dataflow (MODE) and the output kind are template parameters.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "common.h"
+#include "device_utils.h"
+#include "transformer_engine/activation.h"
+#include "transformer_engine/cast.h"
+#include "transformer_engine/transpose.h"
+
+namespace te {
+
+void dbias_finalize_launch(const float *ws, Tensor &dbias, size_t slabs, size_t cols, hipStream_t stream);  // dbias.hip
+
+namespace {
+
+enum : int { kActNone = 0, kActGelu, kActSilu, kActRelu, kActQGelu, kActSRelu, kActSigmoid };
+enum : int { kUnary = 0, kDAct = 1, kGatedFwd = 2, kGatedBwd = 3 };
+enum : int { kOutE4M3 = 0, kOutE5M2 = 1, kOutHP = 2 };
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ref common/util/math.h:21-134
+__device__ __forceinline__ float act_f(int id, float x) {
+  switch (id) {
+    case kActGelu: return x * (0.5f + 0.5f * tanhf(x * (0.79788456f + 0.03567741f * x * x)));
+    case kActSilu: return x * sigmoid_f(x);
+    case kActRelu: return fmaxf(x, 0.f);
+    case kActQGelu: return x * sigmoid_f(1.702f * x);
+    case kActSRelu: return x > 0.f ? x * x : 0.f;
+    case kActSigmoid: return sigmoid_f(x);
+    default: return x;
+  }
+}
+__device__ __forceinline__ float dact_f(int id, float x) {
+  switch (id) {
+    case kActGelu: {
+      const float t = tanhf(0.79788456f * x * (1.f + 0.044715f * x * x));
+      return 0.5f * x * ((1.f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.f + t);
+    }
+    case kActSilu: {
+      const float s = sigmoid_f(x);
+      return x * s * (1.f - s) + s;
+    }
+    case kActRelu: return x > 0.f ? 1.f : 0.f;
+    case kActQGelu: {
+      const float s = sigmoid_f(1.702f * x);
+      return 1.702f * x * s * (1.f - s) + s;
+    }
+    case kActSRelu: return fmaxf(2.f * x, 0.f);
+    case kActSigmoid: {
+      const float s = sigmoid_f(x);
+      return s * (1.f - s);
+    }
+    default: return 1.f;
+  }
+}
+
+struct FusedArgs {
+  const void *in;    // unary: input; d-act / gated: the activation input ([R, H] or [R, 2H])
+  const void *grad;  // d-act / gated backward: incoming gradient [R, H]
+  void *out_c;       // row-wise output ([R, H], gated backward [R, 2H]) or null
+  uint8_t *out_t;    // transposed FP8 output or null
+  const float *scale;
+  float *amax, *scale_inv;
+  float *dbias_part;  // [ceil(R/128)][H] fp32 or null
+  unsigned rows, cols;  // cols = H, the width of the activation
+  unsigned ld_in, ld_out;
+  int in_dtype, out_dtype;
+  int act;
+};
+
+constexpr int kTile = 128;
+
+template <int OK>
+__device__ __forceinline__ uint32_t pack4(float a, float b, float c, float d) {
+  if constexpr (OK == kOutE4M3) return cvt4_fp8<Fp8::E4M3>(a, b, c, d);
+  else return cvt4_fp8<Fp8::E5M2>(a, b, c, d);
+}
+
+template <int OK, int MODE, bool DBIAS>
+__global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) {
+  constexpr bool FP8 = OK != kOutHP;
+  constexpr int NOUT = MODE == kGatedBwd ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) uint8_t tile_t[FP8 ? kTile * kTile : 16];
+  __shared__ float colpart[DBIAS ? 16 : 1][kTile];
+  __shared__ float red[4];
+  const unsigned t = threadIdx.x, cg = t & 15u, rg = t >> 4;
+  const unsigned tiles_c = (a.cols + kTile - 1) / kTile;
+  const size_t tile_r = blockIdx.x / tiles_c, tile_col = blockIdx.x % tiles_c;
+  const size_t row0 = tile_r * kTile + rg * 8, col0 = tile_col * kTile + cg * 8;
+  const bool col_ok = col0 < a.cols;
+  const float scale = (FP8 && a.scale) ? *a.scale : 1.f;
+  float amax = 0.f;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint32_t q[NOUT][8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t r = row0 + i;
+    const bool ok = col_ok && r < a.rows;
+    float x0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, x1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+          g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      load8(a.in, r * a.ld_in + col0, a.in_dtype, x0);
+      if constexpr (MODE == kGatedFwd || MODE == kGatedBwd) load8(a.in, r * a.ld_in + a.cols + col0, a.in_dtype, x1);
+      if constexpr (MODE == kDAct || MODE == kGatedBwd) load8(a.grad, r * a.cols + col0, a.in_dtype, g);
+    }
+    float v[NOUT][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if constexpr (MODE == kUnary) v[0][k] = act_f(a.act, x0[k]);
+      if constexpr (MODE == kDAct) v[0][k] = g[k] * dact_f(a.act, x0[k]);
+      if constexpr (MODE == kGatedFwd) v[0][k] = act_f(a.act, x0[k]) * x1[k];
+      if constexpr (MODE == kGatedBwd) {
+        v[0][k] = dact_f(a.act, x0[k]) * g[k] * x1[k];
+        v[1][k] = g[k] * act_f(a.act, x0[k]);
+      }
+      if (!ok) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) v[o][k] = 0.f;
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) amax = fmaxf(amax, __builtin_fabsf(v[o][k]));
+      if constexpr (DBIAS) cs[k] += v[0][k];
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      if constexpr (FP8) {
+        q[o][i][0] = pack4<OK>(v[o][0] * scale, v[o][1] * scale, v[o][2] * scale, v[o][3] * scale);
+        q[o][i][1] = pack4<OK>(v[o][4] * scale, v[o][5] * scale, v[o][6] * scale, v[o][7] * scale);
+        if (ok && a.out_c) {
+          u32x2 w = {q[o][i][0], q[o][i][1]};
+          *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.out_c) + r * a.ld_out + o * a.cols + col0) = w;
+        }
+      } else {
+        if (ok) store8(a.out_c, r * a.ld_out + o * a.cols + col0, a.out_dtype, v[o]);
+      }
+    }
+  }
+  if constexpr (FP8) {
+    if (a.out_t) {
+      const size_t rows_left = a.rows - tile_r * kTile, cols_left = a.cols - tile_col * kTile;
+      const unsigned vch = static_cast<unsigned>(rows_left >= kTile ? 8 : rows_left / 16);
+      const unsigned vco = static_cast<unsigned>(cols_left >= kTile ? kTile : cols_left);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        if (o) __syncthreads();  // the LDS image is reused
+        store_tile_transposed<true>(tile_t, q[o], t,
+                                    a.out_t + (o * a.cols + tile_col * kTile) * static_cast<size_t>(a.rows) +
+                                        tile_r * kTile,
+                                    a.rows, vch, vco);
+      }
+    }
+  }
+  if constexpr (DBIAS) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) colpart[rg][cg * 8 + k] = cs[k];
+    __syncthreads();
+    if (t < kTile) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += colpart[r][t];
+      const size_t c = tile_col * kTile + t;
+      if (c < a.cols) a.dbias_part[tile_r * a.cols + c] = s;
+    }
+  }
+  if (a.amax) {
+    __syncthreads();
+    amax = block_max<4>(amax, red);
+    if (t == 0) atomic_max_nonneg(a.amax, amax);
+  }
+  if (FP8 && blockIdx.x == 0 && t == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
+}
+
+// Any shape / alignment: one element per thread step, every choice at run time.
+__global__ __launch_bounds__(256) void fused_act_general_kernel(const FusedArgs a, const int mode) {
+  __shared__ float red[4];
+  const bool fp8 = a.out_dtype == kNVTEFloat8E4M3 || a.out_dtype == kNVTEFloat8E5M2;
+  const float scale = (fp8 && a.scale) ? *a.scale : 1.f;
+  const int nout = mode == kGatedBwd ? 2 : 1;
+  float amax = 0.f;
+  const size_t total = static_cast<size_t>(a.rows) * a.cols;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * 256) {
+    const size_t r = i / a.cols, c = i % a.cols;
+    const float x0 = load1(a.in, r * a.ld_in + c, a.in_dtype);
+    const float x1 = (mode == kGatedFwd || mode == kGatedBwd) ? load1(a.in, r * a.ld_in + a.cols + c, a.in_dtype) : 0.f;
+    const float g = (mode == kDAct || mode == kGatedBwd) ? load1(a.grad, i, a.in_dtype) : 0.f;
+    float v[2] = {0.f, 0.f};
+    switch (mode) {
+      case kUnary: v[0] = act_f(a.act, x0); break;
+      case kDAct: v[0] = g * dact_f(a.act, x0); break;
+      case kGatedFwd: v[0] = act_f(a.act, x0) * x1; break;
+      default: v[0] = dact_f(a.act, x0) * g * x1; v[1] = g * act_f(a.act, x0); break;
+    }
+    if (a.dbias_part) atomicAdd(a.dbias_part + c, v[0]);
+    for (int o = 0; o < nout; ++o) {
+      amax = fmaxf(amax, __builtin_fabsf(v[o]));
+      const float y = v[o] * scale;
+      if (a.out_c) store1(a.out_c, r * a.ld_out + o * a.cols + c, a.out_dtype, y);
+      if (a.out_t) store1(a.out_t, (o * a.cols + c) * static_cast<size_t>(a.rows) + r, a.out_dtype, y);
+    }
+  }
+  if (a.amax) {
+    amax = block_max<4>(amax, red);
+    if (threadIdx.x == 0) atomic_max_nonneg(a.amax, amax);
+  }
+  if (fp8 && blockIdx.x == 0 && threadIdx.x == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int OK, int MODE>
+void launch_tile(const FusedArgs &a, bool dbias, unsigned grid, hipStream_t stream) {
+  if constexpr (MODE == kUnary || MODE == kDAct) {
+    if (dbias) {
+      hipLaunchKernelGGL((fused_act_tile_kernel<OK, MODE, true>), dim3(grid), dim3(256), 0, stream, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((fused_act_tile_kernel<OK, MODE, false>), dim3(grid), dim3(256), 0, stream, a);
+}
+
+template <int OK>
+void launch_tile_by_mode(int mode, const FusedArgs &a, bool dbias, unsigned grid, hipStream_t stream) {
+  switch (mode) {
+    case kUnary: launch_tile<OK, kUnary>(a, dbias, grid, stream); break;
+    case kDAct: launch_tile<OK, kDAct>(a, dbias, grid, stream); break;
+    case kGatedFwd: launch_tile<OK, kGatedFwd>(a, dbias, grid, stream); break;
+    default: launch_tile<OK, kGatedBwd>(a, dbias, grid, stream); break;
+  }
+}
+
+}  // namespace
+
+// mode / act: the enums above.  grad may be null (unary, gated forward); dbias + workspace are both
+// null or both given (two-call protocol: an empty workspace only reports its shape).
+void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, Tensor &out, Tensor *dbias,
+                      Tensor *workspace, hipStream_t stream) {
+  const bool gated = mode == kGatedFwd || mode == kGatedBwd;
+  const size_t rows = in.rows();
+  NVTE_CHECK(!gated || in.cols() % 2 == 0, "Gated activation input must have an even last dimension, got ", in.cols());
+  const size_t H = gated ? in.cols() / 2 : in.cols();
+  const size_t out_cols = mode == kGatedBwd ? 2 * H : H;
+  check_input(in, "input");
+  NVTE_CHECK(is_high_precision(in.data.dtype), "Activation input must be FP32/BF16/FP16");
+  if (grad) {
+    check_input(*grad, "grad");
+    NVTE_CHECK(grad->data.dtype == in.data.dtype, "grad and input must have the same dtype");
+    NVTE_CHECK(grad->rows() == rows && grad->cols() == H, "grad has wrong shape (expected ", rows, "x", H, ")");
+  }
+  constexpr size_t kSlab = 128;
+  if (dbias) {
+    NVTE_CHECK(workspace != nullptr, "dbias needs a workspace tensor");
+    if (workspace->data.ptr == nullptr) {
+      workspace->data.shape = NVTEShape{{ceil_div(rows, kSlab), H}, 2};
+      workspace->data.dtype = kNVTEFloat32;
+      return;
+    }
+    NVTE_CHECK(dbias->data.dtype == in.data.dtype, "DBias must have the same type as input.");
+    NVTE_CHECK(dbias->data.shape.ndim == 1 && dbias->data.shape.data[0] == H, "Wrong shape of DBias.");
+    NVTE_CHECK(dbias->data.ptr != nullptr, "DBias is not allocated.");
+    NVTE_CHECK(workspace->data.dtype == kNVTEFloat32 && workspace->data.numel() >= ceil_div(rows, kSlab) * H,
+               "Workspace is too small (need ", ceil_div(rows, kSlab) * H, " fp32 entries)");
+  }
+  check_output(out, "output");
+  NVTE_CHECK(is_tensor_scaling(out.scaling_mode),
+             "fused activation + cast: only high-precision and FP8 per-tensor-scaling outputs are implemented, got ",
+             scaling_mode_name(out.scaling_mode));
+  const DType odt = out.dtype();
+  const bool fp8 = is_fp8(odt);
+  NVTE_CHECK(fp8 || is_high_precision(odt), "Unsupported output dtype ", dtype_name(odt));
+  NVTE_CHECK(fp8 || out.has_data(), "High-precision output needs row-wise data");
+  NVTE_CHECK(out.has_data() || out.has_columnwise_data(), "Output is not allocated");
+  if (out.has_data()) NVTE_CHECK(out.data.numel() == rows * out_cols, "Output has wrong size (expected ", rows, "x", out_cols, ")");
+  if (out.has_columnwise_data()) {
+    NVTE_CHECK(fp8, "A transposed output needs an FP8 dtype");
+    NVTE_CHECK(out.columnwise_data.numel() == rows * out_cols, "Transposed output has wrong size");
+  }
+  NVTE_CHECK(rows < (1ull << 31) && out_cols < (1ull << 31), "tensor too large");
+  if (rows == 0 || H == 0) return;
+  (void)device_info();
+
+  FusedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = in.data.ptr;
+  a.grad = grad ? grad->data.ptr : nullptr;
+  a.out_c = out.data.ptr;
+  a.out_t = static_cast<uint8_t *>(out.columnwise_data.ptr);
+  a.scale = fp8 ? static_cast<const float *>(out.scale.ptr) : nullptr;
+  a.amax = static_cast<float *>(out.amax.ptr);
+  a.scale_inv = fp8 ? static_cast<float *>(out.scale_inv.ptr ? out.scale_inv.ptr : out.columnwise_scale_inv.ptr) : nullptr;
+  a.dbias_part = dbias ? static_cast<float *>(workspace->data.ptr) : nullptr;
+  a.rows = static_cast<unsigned>(rows);
+  a.cols = static_cast<unsigned>(H);
+  a.ld_in = static_cast<unsigned>(in.cols());
+  a.ld_out = static_cast<unsigned>(out_cols);
+  a.in_dtype = in.data.dtype;
+  a.out_dtype = odt;
+  a.act = act;
+
+  const size_t slabs = ceil_div(rows, kSlab);
+  const bool vec = H % 8 == 0 && aligned16(a.in) && (!a.grad || aligned16(a.grad)) && (!a.out_c || aligned16(a.out_c)) &&
+                   (!a.out_t || (aligned16(a.out_t) && rows % 16 == 0)) &&
+                   (fp8 || (H * dtype_bits(odt) / 8) % 16 == 0);
+  if (vec) {
+    const size_t tiles = slabs * ceil_div(H, kTile);
+    NVTE_CHECK(tiles < (1ull << 31), "tensor too large");
+    const unsigned grid = static_cast<unsigned>(tiles);
+    if (odt == kNVTEFloat8E4M3) launch_tile_by_mode<kOutE4M3>(mode, a, dbias != nullptr, grid, stream);
+    else if (odt == kNVTEFloat8E5M2) launch_tile_by_mode<kOutE5M2>(mode, a, dbias != nullptr, grid, stream);
+    else launch_tile_by_mode<kOutHP>(mode, a, dbias != nullptr, grid, stream);
+  } else {
+    if (dbias) NVTE_CHECK_HIP(hipMemsetAsync(a.dbias_part, 0, slabs * H * sizeof(float), stream));
+    const unsigned grid = static_cast<unsigned>(std::min<size_t>(ceil_div(rows * H, 256), static_cast<size_t>(device_info().num_cus) * 16));
+    hipLaunchKernelGGL(fused_act_general_kernel, dim3(grid), dim3(256), 0, stream, a, mode);
+  }
+  NVTE_CHECK_HIP(hipGetLastError());
+  if (dbias) dbias_finalize_launch(a.dbias_part, *dbias, slabs, H, stream);
+}
+
+// nvte_quantize_dbias / nvte_cast_transpose_dbias for FP8 per-tensor-scaling outputs: same kernel with
+// the identity "activation" (the cast and the column sums share ONE read of the input)
+void fused_cast_dbias_launch(const Tensor &in, Tensor &out, Tensor &dbias, Tensor &workspace, hipStream_t stream) {
+  fused_act_launch(kUnary, kActNone, nullptr, in, out, &dbias, &workspace, stream);
+}
+
+}  // namespace te
+
+using namespace te;
+
+extern "C" {
+
+#define TE_UNARY(name, act_id)                                                                          \
+  void name(const NVTETensor input, NVTETensor output, hipStream_t stream) {                            \
+    api_guard(#name, [&] {                                                                              \
+      fused_act_launch(kUnary, act_id, nullptr, *lookup_checked(input), *lookup_checked(output), nullptr, \
+                       nullptr, stream);                                                                \
+    });                                                                                                 \
+  }
+#define TE_DACT(name, act_id)                                                                           \
+  void name(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream) {     \
+    api_guard(#name, [&] {                                                                              \
+      fused_act_launch(kDAct, act_id, lookup_checked(grad), *lookup_checked(input), *lookup_checked(output), \
+                       nullptr, nullptr, stream);                                                       \
+    });                                                                                                 \
+  }
+#define TE_GATED(name, act_id)                                                                          \
+  void name(const NVTETensor input, NVTETensor output, hipStream_t stream) {                            \
+    api_guard(#name, [&] {                                                                              \
+      fused_act_launch(kGatedFwd, act_id, nullptr, *lookup_checked(input), *lookup_checked(output), nullptr, \
+                       nullptr, stream);                                                                \
+    });                                                                                                 \
+  }
+#define TE_DGATED(name, act_id)                                                                         \
+  void name(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream) {     \
+    api_guard(#name, [&] {                                                                              \
+      fused_act_launch(kGatedBwd, act_id, lookup_checked(grad), *lookup_checked(input),                 \
+                       *lookup_checked(output), nullptr, nullptr, stream);                              \
+    });                                                                                                 \
+  }
+#define TE_DBIAS_DACT(name, act_id)                                                                     \
+  void name(const NVTETensor input, const NVTETensor act_input, NVTETensor output, NVTETensor dbias,    \
+            NVTETensor workspace, hipStream_t stream) {                                                 \
+    api_guard(#name, [&] {                                                                              \
+      fused_act_launch(kDAct, act_id, lookup_checked(input), *lookup_checked(act_input),                \
+                       *lookup_checked(output), lookup_checked(dbias), lookup_checked(workspace), stream); \
+    });                                                                                                 \
+  }
+
+TE_UNARY(nvte_gelu, kActGelu)
+TE_UNARY(nvte_silu, kActSilu)
+TE_UNARY(nvte_relu, kActRelu)
+TE_UNARY(nvte_qgelu, kActQGelu)
+TE_UNARY(nvte_srelu, kActSRelu)
+TE_DACT(nvte_dgelu, kActGelu)
+TE_DACT(nvte_dsilu, kActSilu)
+TE_DACT(nvte_drelu, kActRelu)
+TE_DACT(nvte_dqgelu, kActQGelu)
+TE_DACT(nvte_dsrelu, kActSRelu)
+TE_GATED(nvte_glu, kActSigmoid)
+TE_GATED(nvte_geglu, kActGelu)
+TE_GATED(nvte_swiglu, kActSilu)
+TE_GATED(nvte_reglu, kActRelu)
+TE_GATED(nvte_qgeglu, kActQGelu)
+TE_GATED(nvte_sreglu, kActSRelu)
+TE_DGATED(nvte_dglu, kActSigmoid)
+TE_DGATED(nvte_dgeglu, kActGelu)
+TE_DGATED(nvte_dswiglu, kActSilu)
+TE_DGATED(nvte_dreglu, kActRelu)
+TE_DGATED(nvte_dqgeglu, kActQGelu)
+TE_DGATED(nvte_dsreglu, kActSRelu)
+TE_DBIAS_DACT(nvte_quantize_dbias_dgelu, kActGelu)
+TE_DBIAS_DACT(nvte_quantize_dbias_dsilu, kActSilu)
+TE_DBIAS_DACT(nvte_quantize_dbias_drelu, kActRelu)
+TE_DBIAS_DACT(nvte_quantize_dbias_dqgelu, kActQGelu)
+TE_DBIAS_DACT(nvte_quantize_dbias_dsrelu, kActSRelu)
+TE_DBIAS_DACT(nvte_cast_transpose_dbias_dgelu, kActGelu)
+TE_DBIAS_DACT(nvte_cast_transpose_dbias_dsilu, kActSilu)
+TE_DBIAS_DACT(nvte_cast_transpose_dbias_drelu, kActRelu)
+TE_DBIAS_DACT(nvte_cast_transpose_dbias_dqgelu, kActQGelu)
+TE_DBIAS_DACT(nvte_cast_transpose_dbias_dsrelu, kActSRelu)
+
+// ref transpose.h:242-318: (input = grad, act_input, output)
+#define TE_DGATED_CT(name, act_id)                                                                      \
+  void name(const NVTETensor input, const NVTETensor act_input, NVTETensor output, hipStream_t stream) { \
+    api_guard(#name, [&] {                                                                              \
+      fused_act_launch(kGatedBwd, act_id, lookup_checked(input), *lookup_checked(act_input),            \
+                       *lookup_checked(output), nullptr, nullptr, stream);                              \
+    });                                                                                                 \
+  }
+TE_DGATED_CT(nvte_dgeglu_cast_transpose, kActGelu)
+TE_DGATED_CT(nvte_dswiglu_cast_transpose, kActSilu)
+TE_DGATED_CT(nvte_dreglu_cast_transpose, kActRelu)
+TE_DGATED_CT(nvte_dqgeglu_cast_transpose, kActQGelu)
+TE_DGATED_CT(nvte_dsreglu_cast_transpose, kActSRelu)
+
+}  // extern "C"

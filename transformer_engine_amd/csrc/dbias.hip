@@ -90,4 +90,27 @@ void dbias_launch(const Tensor &in, Tensor &dbias, Tensor &workspace, hipStream_
   NVTE_CHECK_HIP(hipGetLastError());
 }
 
+// Slab reduce alone: for kernels that produce the [slabs, cols] fp32 partials themselves (activation.hip).
+void dbias_finalize_launch(const float *ws, Tensor &dbias, size_t slabs, size_t cols, hipStream_t stream) {
+  if (cols == 0) return;
+  const dim3 g2(static_cast<unsigned>(ceil_div(cols, 256)));
+  switch (dbias.data.dtype) {
+    case kNVTEBFloat16:
+      hipLaunchKernelGGL(colsum_final_kernel<bf16_t>, g2, dim3(256), 0, stream, ws,
+                         static_cast<bf16_t *>(dbias.data.ptr), slabs, cols);
+      break;
+    case kNVTEFloat16:
+      hipLaunchKernelGGL(colsum_final_kernel<f16_t>, g2, dim3(256), 0, stream, ws,
+                         static_cast<f16_t *>(dbias.data.ptr), slabs, cols);
+      break;
+    case kNVTEFloat32:
+      hipLaunchKernelGGL(colsum_final_kernel<float>, g2, dim3(256), 0, stream, ws,
+                         static_cast<float *>(dbias.data.ptr), slabs, cols);
+      break;
+    default:
+      NVTE_ERROR("Unsupported dbias dtype ", dtype_name(dbias.data.dtype));
+  }
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+
 }  // namespace te

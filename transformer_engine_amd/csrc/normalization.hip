@@ -28,75 +28,6 @@
 namespace te {
 namespace {
 
-// ---------------------------------------------------------------- 8-element typed access
-__device__ __forceinline__ void load8(const void *base, size_t idx, int dtype, float (&f)[8]) {
-  switch (dtype) {
-    case kNVTEBFloat16: Load8<bf16_t>::run(static_cast<const bf16_t *>(base) + idx, f); break;
-    case kNVTEFloat16: Load8<f16_t>::run(static_cast<const f16_t *>(base) + idx, f); break;
-    default: Load8<float>::run(static_cast<const float *>(base) + idx, f); break;
-  }
-}
-// plain (cached) loads for the small per-column vectors
-__device__ __forceinline__ float load1(const void *base, size_t idx, int dtype) {
-  switch (dtype) {
-    case kNVTEBFloat16: return widen(static_cast<const bf16_t *>(base)[idx]);
-    case kNVTEFloat16: return widen(static_cast<const f16_t *>(base)[idx]);
-    default: return static_cast<const float *>(base)[idx];
-  }
-}
-__device__ __forceinline__ void store1(void *base, size_t idx, int dtype, float v) {
-  switch (dtype) {
-    case kNVTEBFloat16: narrow(v, static_cast<bf16_t *>(base)[idx]); break;
-    case kNVTEFloat16: narrow(v, static_cast<f16_t *>(base)[idx]); break;
-    case kNVTEFloat8E4M3: static_cast<uint8_t *>(base)[idx] = cvt1_fp8<Fp8::E4M3>(v); break;
-    case kNVTEFloat8E5M2: static_cast<uint8_t *>(base)[idx] = cvt1_fp8<Fp8::E5M2>(v); break;
-    default: static_cast<float *>(base)[idx] = v; break;
-  }
-}
-// value after rounding to the output dtype (amax of a non-FP8 output, ref rmsnorm_fwd_kernels.cuh:113-117)
-__device__ __forceinline__ float round_to(float v, int dtype) {
-  switch (dtype) {
-    case kNVTEBFloat16: { bf16_t o; narrow(v, o); return widen(o); }
-    case kNVTEFloat16: { f16_t o; narrow(v, o); return widen(o); }
-    default: return v;
-  }
-}
-__device__ __forceinline__ void store8(void *base, size_t idx, int dtype, const float (&v)[8]) {
-  switch (dtype) {
-    case kNVTEFloat8E4M3: {
-      u32x2 o = {cvt4_fp8<Fp8::E4M3>(v[0], v[1], v[2], v[3]), cvt4_fp8<Fp8::E4M3>(v[4], v[5], v[6], v[7])};
-      *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(base) + idx) = o;
-      break;
-    }
-    case kNVTEFloat8E5M2: {
-      u32x2 o = {cvt4_fp8<Fp8::E5M2>(v[0], v[1], v[2], v[3]), cvt4_fp8<Fp8::E5M2>(v[4], v[5], v[6], v[7])};
-      *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(base) + idx) = o;
-      break;
-    }
-    case kNVTEBFloat16: {
-      bf16_t o[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) narrow(v[k], o[k]);
-      *reinterpret_cast<u32x4 *>(static_cast<bf16_t *>(base) + idx) = *reinterpret_cast<const u32x4 *>(o);
-      break;
-    }
-    case kNVTEFloat16: {
-      f16_t o[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) narrow(v[k], o[k]);
-      *reinterpret_cast<u32x4 *>(static_cast<f16_t *>(base) + idx) = *reinterpret_cast<const u32x4 *>(o);
-      break;
-    }
-    default: {
-      f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-      float *p = static_cast<float *>(base) + idx;
-      *reinterpret_cast<f32x4 *>(p) = lo;
-      *reinterpret_cast<f32x4 *>(p + 4) = hi;
-      break;
-    }
-  }
-}
-
 // Sum of (a, b) over the 256 threads of the workgroup, result in every thread.  `red` has
 // 2 x 4 x 2 floats; `phase` alternates so that consecutive reductions need one barrier each.
 __device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[4][2], unsigned &phase) {

@@ -16,6 +16,12 @@ namespace te {
 
 bool dbias_workspace_query(const Tensor &in, Tensor &workspace);                             // dbias.hip
 void dbias_launch(const Tensor &in, Tensor &dbias, Tensor &workspace, hipStream_t stream);   // dbias.hip
+// activation.hip: cast (+transpose) and the column sums in ONE pass, FP8 per-tensor-scaling outputs
+void fused_cast_dbias_launch(const Tensor &in, Tensor &out, Tensor &dbias, Tensor &workspace, hipStream_t stream);
+static bool fused_dbias_ok(const Tensor &in, const Tensor &out) {
+  return is_tensor_scaling(out.scaling_mode) && is_fp8(out.dtype()) && out.has_data() &&
+         is_high_precision(in.data.dtype);
+}
 
 // The OUTPUT tensor's format picks the kernel (ref dispatch/quantize.cuh:63-93).
 void quantize_dispatch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream) {
@@ -111,6 +117,10 @@ void nvte_quantize_dbias(const NVTETensor input, NVTETensor output, NVTETensor d
     Tensor &db = *lookup_checked(dbias);
     Tensor &ws = *lookup_checked(workspace);
     check_input(in, "cast_input");
+    if (fused_dbias_ok(in, out)) {
+      fused_cast_dbias_launch(in, out, db, ws, stream);
+      return;
+    }
     if (dbias_workspace_query(in, ws)) return;
     quantize_dispatch(in, nullptr, out, stream);
     dbias_launch(in, db, ws, stream);
@@ -167,6 +177,10 @@ void nvte_cast_transpose_dbias(const NVTETensor input, NVTETensor output, NVTETe
     Tensor &db = *lookup_checked(dbias);
     Tensor &ws = *lookup_checked(workspace);
     check_input(in, "cast_transpose_input");
+    if (fused_dbias_ok(in, out)) {
+      fused_cast_dbias_launch(in, out, db, ws, stream);
+      return;
+    }
     if (dbias_workspace_query(in, ws)) return;
     cast_transpose_launch(in, nullptr, out, stream);
     dbias_launch(in, db, ws, stream);
