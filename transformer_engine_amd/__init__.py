@@ -10,6 +10,7 @@ Package layout (only what the path needs):
   distributed.py  TP/SP collectives on RCCL + comm/GEMM overlap
   grouped.py / grouped_linear.py  grouped (MoE) tensors, quantize and GEMM with device-side splits
   normalization.py  LayerNorm / RMSNorm with fused FP8 output (LayerNormLinear lives in linear.py)
+  activation.py  plain / gated activations fused with the FP8 cast, transpose and dbias
 """
 from ._lib import NVTEError, api, version  # noqa: F401
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor,  # noqa: F401
