@@ -290,7 +290,50 @@ def main():
         t_dgrad = time_kernel(lambda: general_gemm(w8, dy8, layout="NN", out=dx, grad=True), it)
         t_wgrad = time_kernel(lambda: general_gemm(x8, dy8, layout="NT", out=dw, grad=True), it)
         gemm_flops = 2.0 * M * N * K
-        gemm_avg_ms = (t_fprop + t_dgrad + t_wgrad) / 3.0
+        # ---- the same kernels timed INSIDE the step: args.steps eager steps of the timed workload with a
+        # HIP event pair (on the launch stream) around every hot launch.  These are the durations the
+        # roofline uses - they include the cache state a real step leaves behind (a kernel launched
+        # back to back on the same operands finds part of them in the 256 MiB Infinity Cache) and they
+        # are what `rocprofv3 --kernel-trace --stats -- python3 bench.py` averages (profiles/).
+        in_step = {k: [] for k in ("cast_transpose_x", "gemm_fprop", "cast_transpose_dy", "gemm_dgrad", "gemm_wgrad")}
+
+        class rec:
+            def __init__(self, role):
+                self.role = role
+                self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def __enter__(self):
+                self.a.record()
+
+            def __exit__(self, *exc):
+                self.b.record()
+                in_step[self.role].append((self.a, self.b))
+
+        def instrumented_step():
+            qi.set_usage(rowwise=True, columnwise=True)
+            with rec("cast_transpose_x"):
+                sx8 = qi(x)
+            with rec("gemm_fprop"):
+                general_gemm(st.weight_cache, sx8, out_dtype=torch.bfloat16, layout="TN")
+            st.update_fwd()
+            qg.set_usage(rowwise=True, columnwise=True)
+            with rec("cast_transpose_dy"):
+                sdy8 = qg(dy)
+            with rec("gemm_dgrad"):
+                general_gemm(st.weight_cache, sdy8, out_dtype=torch.bfloat16, layout="NN", grad=True)
+            with rec("gemm_wgrad"):
+                general_gemm(sx8, sdy8, out_dtype=torch.bfloat16, layout="NT", grad=True)
+            st.update_bwd()
+
+        for _ in range(3):
+            instrumented_step()
+        for v in in_step.values():
+            v.clear()
+        for _ in range(args.steps):
+            instrumented_step()
+        torch.cuda.synchronize()
+        step_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in in_step.items()}
+        gemm_avg_ms = (step_ms["gemm_fprop"] + step_ms["gemm_dgrad"] + step_ms["gemm_wgrad"]) / 3.0
         achieved = gemm_flops / (gemm_avg_ms * 1e-3) / 1e12
         traffic = load_traffic()
         default_shape = (M, K, N) == (8192, 4096, 14336)   # the committed passes were taken on these shapes
@@ -301,13 +344,19 @@ def main():
                               "traffic_unit": "bytes/launch (fabric side: HBM + Infinity Cache; fprop/dgrad/wgrad mean)",
                               "kernel": "gemm_fp8_kernel (fprop/dgrad/wgrad average, 2*M*N*K FLOP per launch)"}
         ct_bytes = dy.numel() * 4.0      # 2 B read + 1 B rowwise + 1 B transposed per bf16 element
-        ct_gbps = ct_bytes / (t_ct_dy * 1e-3) / 1e9
+        ct_gbps = ct_bytes / (step_ms["cast_transpose_dy"] * 1e-3) / 1e9
         result["roofline_cast_transpose"] = {"bound": "hbm", "achieved": ct_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                              "frac": ct_gbps / PEAK_HBM_GBPS,
                                              "traffic": traffic_of(traffic, "cast_transpose_dy") if default_shape else None,
                                              "algorithmic_bytes": ct_bytes,
                                              "kernel": "cast_transpose_tile_kernel on dY [8192,14336] bf16->e5m2, 4 B/element"}
+        result["roofline"]["launch_ms"] = {k: step_ms[k] for k in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")}
+        result["roofline"]["timing"] = "HIP events around each launch inside args.steps eager steps of the timed workload"
+        result["roofline_cast_transpose"]["launch_ms"] = step_ms["cast_transpose_dy"]
         result["extra"] = {
+            "in_step_ms": step_ms,
+            "isolated_note": "gemm_ms / cast_transpose_ms below: the same kernel launched back to back on resident "
+                             "operands (upper bound: inputs partly stay in the Infinity Cache)",
             "gemm_ms": {"fprop": t_fprop, "dgrad": t_dgrad, "wgrad": t_wgrad},
             "gemm_tflops": {"fprop": gemm_flops / t_fprop / 1e9, "dgrad": gemm_flops / t_dgrad / 1e9,
                             "wgrad": gemm_flops / t_wgrad / 1e9},
