@@ -30,6 +30,7 @@
 namespace te {
 
 void dbias_finalize_launch(const float *ws, Tensor &dbias, size_t slabs, size_t cols, hipStream_t stream);  // dbias.hip
+bool cast_transpose_dbias_tile_launch(const Tensor &in, Tensor &out, float *part, hipStream_t stream);     // cast_transpose.hip
 
 namespace {
 
@@ -37,12 +38,20 @@ enum : int { kActNone = 0, kActGelu, kActSilu, kActRelu, kActQGelu, kActSRelu, k
 enum : int { kUnary = 0, kDAct = 1, kGatedFwd = 2, kGatedBwd = 3 };
 enum : int { kOutE4M3 = 0, kOutE5M2 = 1, kOutHP = 2 };
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// exp through the hardware 2^x and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): the library expf /
+// tanhf cost 20-40 instructions per value, which made gelu -> FP8 compute-bound (138 us against 82 us
+// for relu on the same tensor).  tanh never appears as such: with p = sigmoid(2u),
+//   0.5 (1 + tanh u) = p        and        1 - tanh^2 u = 4 p (1 - p),
+// so gelu and dgelu (ref math.h:21-32) are evaluated without the cancellation of 1 + tanh(u) for
+// very negative u - p keeps its RELATIVE accuracy there (2^+big -> rcp -> tiny, saturating to 0).
+__device__ __forceinline__ float sigmoid_f(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // ref common/util/math.h:21-134
 __device__ __forceinline__ float act_f(int id, float x) {
   switch (id) {
-    case kActGelu: return x * (0.5f + 0.5f * tanhf(x * (0.79788456f + 0.03567741f * x * x)));
+    case kActGelu: return x * sigmoid_f(2.f * x * (0.79788456f + 0.03567741f * x * x));
     case kActSilu: return x * sigmoid_f(x);
     case kActRelu: return fmaxf(x, 0.f);
     case kActQGelu: return x * sigmoid_f(1.702f * x);
@@ -54,8 +63,8 @@ __device__ __forceinline__ float act_f(int id, float x) {
 __device__ __forceinline__ float dact_f(int id, float x) {
   switch (id) {
     case kActGelu: {
-      const float t = tanhf(0.79788456f * x * (1.f + 0.044715f * x * x));
-      return 0.5f * x * ((1.f - t * t) * (0.79788456f + 0.1070322243f * x * x)) + 0.5f * (1.f + t);
+      const float p = sigmoid_f(2.f * 0.79788456f * x * (1.f + 0.044715f * x * x));
+      return 2.f * x * (p * (1.f - p) * (0.79788456f + 0.1070322243f * x * x)) + p;
     }
     case kActSilu: {
       const float s = sigmoid_f(x);
@@ -142,7 +151,10 @@ struct Raw8<float> {
   }
 };
 
-template <typename IT, int OK, int MODE, bool DBIAS>
+// ACT is a template parameter on purpose: dispatching on a run-time id inside the kernel (even once per
+// workgroup around seven inlined bodies) ends up as a branch tree PER ELEMENT after LLVM merges the
+// bodies back together - measured 103 us instead of 76 us for relu -> FP8 + transpose.
+template <typename IT, int OK, int MODE, int ACT, bool DBIAS>
 __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) {
   constexpr bool FP8 = OK != kOutHP;
   constexpr int NOUT = MODE == kGatedBwd ? 2 : 1;
@@ -170,8 +182,6 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
   float amax = 0.f;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint32_t q[NOUT][8][2];
-  auto compute = [&](auto act_tag) __attribute__((always_inline)) {
-  constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const size_t r = row0 + i;
@@ -211,16 +221,6 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
       }
     }
   }
-  };
-  switch (a.act) {
-    case kActGelu: compute(std::integral_constant<int, kActGelu>{}); break;
-    case kActSilu: compute(std::integral_constant<int, kActSilu>{}); break;
-    case kActRelu: compute(std::integral_constant<int, kActRelu>{}); break;
-    case kActQGelu: compute(std::integral_constant<int, kActQGelu>{}); break;
-    case kActSRelu: compute(std::integral_constant<int, kActSRelu>{}); break;
-    case kActSigmoid: compute(std::integral_constant<int, kActSigmoid>{}); break;
-    default: compute(std::integral_constant<int, kActNone>{}); break;
-  }
   if constexpr (FP8) {
     if (a.out_t) {
       const size_t rows_left = a.rows - tile_r * kTile, cols_left = a.cols - tile_col * kTile;
@@ -229,10 +229,10 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
         if (o) __syncthreads();  // the LDS image is reused
-        store_tile_transposed<true>(tile_t, q[o], t,
-                                    a.out_t + (o * a.cols + tile_col * kTile) * static_cast<size_t>(a.rows) +
-                                        tile_r * kTile,
-                                    a.rows, vch, vco);
+        uint8_t *dst_t = a.out_t + (o * a.cols + tile_col * kTile) * static_cast<size_t>(a.rows) + tile_r * kTile;
+        // whole tiles (block-uniform test) take the unguarded store: its four LDS reads issue back to back
+        if (vch == 8 && vco == kTile) store_tile_transposed<false>(tile_t, q[o], t, dst_t, a.rows);
+        else store_tile_transposed<true>(tile_t, q[o], t, dst_t, a.rows, vch, vco);
       }
     }
   }
@@ -293,25 +293,44 @@ __global__ __launch_bounds__(256) void fused_act_general_kernel(const FusedArgs 
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <typename IT, int OK, int MODE>
+template <typename IT, int OK, int MODE, int ACT>
 void launch_tile(const FusedArgs &a, bool dbias, unsigned grid, hipStream_t stream) {
-  if constexpr ((MODE == kUnary || MODE == kDAct) && OK != kOutHP) {
-    if (dbias) {
-      hipLaunchKernelGGL((fused_act_tile_kernel<IT, OK, MODE, true>), dim3(grid), dim3(256), 0, stream, a);
-      return;
+  // combinations that exist: the identity only as a plain cast, the sigmoid only as the GLU gate
+  constexpr bool valid = (ACT != kActNone || MODE == kUnary) && (ACT != kActSigmoid || MODE == kGatedFwd || MODE == kGatedBwd);
+  if constexpr (!valid) {
+    NVTE_ERROR("invalid activation / mode combination");
+  } else {
+    if constexpr ((MODE == kUnary || MODE == kDAct) && OK != kOutHP) {
+      if (dbias) {
+        hipLaunchKernelGGL((fused_act_tile_kernel<IT, OK, MODE, ACT, true>), dim3(grid), dim3(256), 0, stream, a);
+        return;
+      }
     }
+    NVTE_CHECK(!dbias, "dbias is fused for FP8 outputs of the plain / d-act modes only");
+    hipLaunchKernelGGL((fused_act_tile_kernel<IT, OK, MODE, ACT, false>), dim3(grid), dim3(256), 0, stream, a);
   }
-  NVTE_CHECK(!dbias, "dbias is fused for FP8 outputs of the plain / d-act modes only");
-  hipLaunchKernelGGL((fused_act_tile_kernel<IT, OK, MODE, false>), dim3(grid), dim3(256), 0, stream, a);
+}
+
+template <typename IT, int OK, int MODE>
+void launch_tile_by_act(const FusedArgs &a, bool dbias, unsigned grid, hipStream_t stream) {
+  switch (a.act) {
+    case kActGelu: launch_tile<IT, OK, MODE, kActGelu>(a, dbias, grid, stream); break;
+    case kActSilu: launch_tile<IT, OK, MODE, kActSilu>(a, dbias, grid, stream); break;
+    case kActRelu: launch_tile<IT, OK, MODE, kActRelu>(a, dbias, grid, stream); break;
+    case kActQGelu: launch_tile<IT, OK, MODE, kActQGelu>(a, dbias, grid, stream); break;
+    case kActSRelu: launch_tile<IT, OK, MODE, kActSRelu>(a, dbias, grid, stream); break;
+    case kActSigmoid: launch_tile<IT, OK, MODE, kActSigmoid>(a, dbias, grid, stream); break;
+    default: launch_tile<IT, OK, MODE, kActNone>(a, dbias, grid, stream); break;
+  }
 }
 
 template <typename IT, int OK>
 void launch_tile_by_mode(int mode, const FusedArgs &a, bool dbias, unsigned grid, hipStream_t stream) {
   switch (mode) {
-    case kUnary: launch_tile<IT, OK, kUnary>(a, dbias, grid, stream); break;
-    case kDAct: launch_tile<IT, OK, kDAct>(a, dbias, grid, stream); break;
-    case kGatedFwd: launch_tile<IT, OK, kGatedFwd>(a, dbias, grid, stream); break;
-    default: launch_tile<IT, OK, kGatedBwd>(a, dbias, grid, stream); break;
+    case kUnary: launch_tile_by_act<IT, OK, kUnary>(a, dbias, grid, stream); break;
+    case kDAct: launch_tile_by_act<IT, OK, kDAct>(a, dbias, grid, stream); break;
+    case kGatedFwd: launch_tile_by_act<IT, OK, kGatedFwd>(a, dbias, grid, stream); break;
+    default: launch_tile_by_act<IT, OK, kGatedBwd>(a, dbias, grid, stream); break;
   }
 }
 
@@ -393,6 +412,12 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
   a.act = act;
 
   const size_t slabs = ceil_div(rows, kSlab);
+  // plain cast + transpose + dbias on whole tiles: the tuned cast_transpose tile kernel itself
+  if (mode == kUnary && act == kActNone && dbias && fp8 &&
+      cast_transpose_dbias_tile_launch(in, out, a.dbias_part, stream)) {
+    dbias_finalize_launch(a.dbias_part, *dbias, slabs, H, stream);
+    return;
+  }
   const bool vec = !(dbias && !fp8) && H % 8 == 0 && aligned16(a.in) && (!a.grad || aligned16(a.grad)) && (!a.out_c || aligned16(a.out_c)) &&
                    (!a.out_t || (aligned16(a.out_t) && rows % 16 == 0)) &&
                    (fp8 || (H * dtype_bits(odt) / 8) % 16 == 0);

@@ -30,15 +30,20 @@ constexpr int kCtThreads = 256;
 
 // ---------------------------------------------------------------- aligned 128x128 tile kernel
 // Requires rows % 128 == 0, cols % 128 == 0, 16-byte aligned base pointers.
-template <typename IT, Fp8 F>
+// DBIAS: additionally leaves the tile's column sums (over its 128 rows, of the UNSCALED input) in
+// dbias_part[tile_r][col] - the [ceil(R/128), C] fp32 workspace of nvte_quantize_dbias, reduced by
+// dbias.hip afterwards: cast, transpose and bias gradient from ONE read of dY.
+template <typename IT, Fp8 F, bool DBIAS = false>
 __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
     const IT *__restrict__ in, const float *__restrict__ noop, uint8_t *__restrict__ out_c,
     uint8_t *__restrict__ out_t, const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
-    float *__restrict__ scale_inv_ptr, const size_t rows, const size_t cols, const unsigned tiles_c) {
+    float *__restrict__ scale_inv_ptr, const size_t rows, const size_t cols, const unsigned tiles_c,
+    float *__restrict__ dbias_part = nullptr) {
   if (noop_set(noop)) return;
 
   __shared__ __attribute__((aligned(16))) uint8_t tile_t[kTile * kTile];
   __shared__ float red[kCtThreads / kWave];
+  __shared__ float colpart[DBIAS ? 16 : 1][kTile];
 
   const unsigned t = threadIdx.x;
   const unsigned cg = t & 15u;   // 8-column group
@@ -64,6 +69,15 @@ __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
       q[i][0] = cvt4_fp8<F>(f[i][0] * scale, f[i][1] * scale, f[i][2] * scale, f[i][3] * scale);
       q[i][1] = cvt4_fp8<F>(f[i][4] * scale, f[i][5] * scale, f[i][6] * scale, f[i][7] * scale);
     }
+    if constexpr (DBIAS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float c = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c += f[i][j];
+        colpart[rg][cg * 8 + j] = c;
+      }
+    }
   }
 
   // rowwise output straight from registers
@@ -75,6 +89,16 @@ __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
 
   // transposed output through the LDS image (device_utils.h)
   store_tile_transposed(tile_t, q, t, out_t + (tile_col * kTile) * rows + tile_r * kTile, rows);
+
+  if constexpr (DBIAS) {
+    // colpart was written before the barrier inside store_tile_transposed
+    if (t < kTile) {
+      float c = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c += colpart[r][t];
+      dbias_part[tile_r * cols + tile_col * kTile + t] = c;
+    }
+  }
 
   if (amax_ptr != nullptr) {
     amax = block_max<kCtThreads / kWave>(amax, red);
@@ -359,6 +383,35 @@ void cast_transpose_launch(const Tensor &in, const float *noop, Tensor &out, hip
       launch_general_by_out<IT>(in, noop, out, true, rows, cols, stream);
     }
   });
+}
+
+// Tile-aligned cast + transpose + per-slab column sums; returns false when the shape / alignment needs
+// the general fused kernel of activation.hip instead.  `part` = [rows/128, cols] fp32.
+bool cast_transpose_dbias_tile_launch(const Tensor &in, Tensor &out, float *part, hipStream_t stream) {
+  const size_t rows = in.rows(), cols = in.cols();
+  if (!(is_fp8(out.data.dtype) && out.has_data() && out.has_columnwise_data() && rows % kTile == 0 &&
+        cols % kTile == 0 && rows > 0 && cols > 0 && aligned16(in.data.ptr) && aligned16(out.data.ptr) &&
+        aligned16(out.columnwise_data.ptr)))
+    return false;
+  const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
+  const size_t nblk = (rows / kTile) * tiles_c;
+  if (nblk >= (1ull << 31)) return false;
+  TE_SWITCH_IN(in.data.dtype, IT, {
+    if (out.data.dtype == kNVTEFloat8E4M3)
+      hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, Fp8::E4M3, true>), dim3(nblk), dim3(kCtThreads), 0, stream,
+                         static_cast<const IT *>(in.data.ptr), static_cast<const float *>(nullptr),
+                         static_cast<uint8_t *>(out.data.ptr), static_cast<uint8_t *>(out.columnwise_data.ptr),
+                         static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
+                         static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c, part);
+    else
+      hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, Fp8::E5M2, true>), dim3(nblk), dim3(kCtThreads), 0, stream,
+                         static_cast<const IT *>(in.data.ptr), static_cast<const float *>(nullptr),
+                         static_cast<uint8_t *>(out.data.ptr), static_cast<uint8_t *>(out.columnwise_data.ptr),
+                         static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
+                         static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c, part);
+  });
+  NVTE_CHECK_HIP(hipGetLastError());
+  return true;
 }
 
 // rowwise-only cast (ref quantize_fp8.cuh:510-573 + vectorized_pointwise.h:176-227)
