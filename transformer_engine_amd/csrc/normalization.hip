@@ -28,6 +28,28 @@
 namespace te {
 namespace {
 
+// 8 values -> 8 elements of type T (one 16-byte store for 16-bit types)
+template <typename T>
+__device__ __forceinline__ void store8_t(T *p, const float (&v)[8]) {
+  if constexpr (sizeof(T) == 4) {
+    f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4 *>(p) = lo;
+    *reinterpret_cast<f32x4 *>(p + 4) = hi;
+  } else {
+    T o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) narrow(v[k], o[k]);
+    *reinterpret_cast<u32x4 *>(p) = *reinterpret_cast<const u32x4 *>(o);
+  }
+}
+template <typename T>
+__device__ __forceinline__ float round_as(float v) {
+  T o;
+  narrow(v, o);
+  return widen(o);
+}
+enum : int { kZE4M3 = 0, kZE5M2 = 1, kZSame = 2 };  // output kind of the vector forward kernel
+
 // Sum of (a, b) over the 256 threads of the workgroup, result in every thread.  `red` has
 // 2 x 4 x 2 floats; `phase` alternates so that consecutive reductions need one barrier each.
 __device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[4][2], unsigned &phase) {
@@ -59,13 +81,16 @@ struct NormFwdArgs {
   int zero_centered;
 };
 
-template <int NV, bool LN>
+// IT (input) and ZK (output kind) are template parameters: a run-time dtype switch inside the unrolled
+// vector loops becomes a branch tree per vector and serialises the loads of a row.
+template <int NV, bool LN, typename IT, int ZK>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
   __shared__ float red[2][4][2];
   __shared__ float red_max[4];
   unsigned phase = 0;
   const unsigned tid = threadIdx.x;
-  const bool fp8_out = a.z_dtype == kNVTEFloat8E4M3 || a.z_dtype == kNVTEFloat8E5M2;
+  constexpr bool fp8_out = ZK != kZSame;
+  const IT *xin = static_cast<const IT *>(a.x);
   const float scale = (fp8_out && a.scale) ? *a.scale : 1.f;
   const float rn = 1.f / static_cast<float>(a.cols);
   float g[NV][8], b[NV][8];
@@ -87,7 +112,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
     for (int v = 0; v < NV; ++v) {
       const unsigned c = (v * 256 + tid) * 8;
       if (c < a.cols) {
-        load8(a.x, base + c, a.x_dtype, x[v]);
+        Load8<IT>::run(xin + base + c, x[v]);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[v][k] = 0.f;
@@ -128,15 +153,23 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float t = (x[v][k] - mean) * rs * g[v][k] + b[v][k];
-        if (fp8_out) {
+        if constexpr (fp8_out) {
           amax = fmaxf(amax, __builtin_fabsf(t));
           t *= scale;
-        } else if (a.amax) {
-          amax = fmaxf(amax, __builtin_fabsf(round_to(t, a.z_dtype)));
+        } else {
+          if (a.amax) amax = fmaxf(amax, __builtin_fabsf(round_as<IT>(t)));
         }
         o[k] = t;
       }
-      store8(a.z, base + c, a.z_dtype, o);
+      if constexpr (ZK == kZE4M3) {
+        u32x2 w = {cvt4_fp8<Fp8::E4M3>(o[0], o[1], o[2], o[3]), cvt4_fp8<Fp8::E4M3>(o[4], o[5], o[6], o[7])};
+        *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.z) + base + c) = w;
+      } else if constexpr (ZK == kZE5M2) {
+        u32x2 w = {cvt4_fp8<Fp8::E5M2>(o[0], o[1], o[2], o[3]), cvt4_fp8<Fp8::E5M2>(o[4], o[5], o[6], o[7])};
+        *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.z) + base + c) = w;
+      } else {
+        store8_t<IT>(static_cast<IT *>(a.z) + base + c, o);
+      }
     }
   }
   if (a.amax) {
@@ -146,7 +179,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
   if (fp8_out && blockIdx.x == 0 && tid == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
 }
 
-// Any shape / alignment: three scalar passes over the row.
+// Any shape / alignment / dtype combination: three scalar passes over the row.
 template <bool LN>
 __global__ __launch_bounds__(256) void norm_fwd_general_kernel(const NormFwdArgs a) {
   __shared__ float red[2][4][2];
@@ -214,7 +247,7 @@ struct NormBwdArgs {
 
 // dx = rs * (dy - mean(dy*y) * y - mean(dy)) (+ add), dy = gamma' * dz, y = (x - mu) * rs
 // (ref tests/cpp/operator/test_normalization.h:140-190); per-workgroup partial dgamma / dbeta.
-template <int NV, bool LN>
+template <int NV, bool LN, typename IT>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
   __shared__ float red[2][4][2];
   unsigned phase = 0;
@@ -241,8 +274,8 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
       const unsigned c = (v * 256 + tid) * 8;
       float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dzv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (c < a.cols) {
-        load8(a.x, base + c, a.x_dtype, xv);
-        load8(a.dz, base + c, a.w_dtype, dzv);
+        Load8<IT>::run(static_cast<const IT *>(a.x) + base + c, xv);
+        Load8<IT>::run(static_cast<const IT *>(a.dz) + base + c, dzv);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -263,10 +296,10 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
       const unsigned c = (v * 256 + tid) * 8;
       if (c >= a.cols) continue;
       float o[8], ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.add) load8(a.add, base + c, a.w_dtype, ad);
+      if (a.add) Load8<IT>::run(static_cast<const IT *>(a.add) + base + c, ad);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = ad[k] + rs * (dy[v][k] - mdyy * y[v][k] - mdy);
-      store8(a.dx, base + c, a.x_dtype, o);
+      store8_t<IT>(static_cast<IT *>(a.dx) + base + c, o);
     }
   }
   float *pg = a.part + static_cast<size_t>(blockIdx.x) * 2 * a.cols;
@@ -360,35 +393,67 @@ unsigned norm_grid(size_t rows, unsigned per_cu) {
 
 bool shape_is_2d(const Buf &b) { return b.shape.ndim == 2; }
 
+template <bool LN, typename IT, int ZK>
+void launch_fwd_vec(const NormFwdArgs &args, hipStream_t stream) {
+  const unsigned per_cu = args.cols <= 2048 ? 8 : args.cols <= 4096 ? 6 : args.cols <= 8192 ? 4 : 2;
+  const dim3 grid(norm_grid(args.rows, per_cu)), block(256);
+  if (args.cols <= 2048) {
+    hipLaunchKernelGGL((norm_fwd_kernel<1, LN, IT, ZK>), grid, block, 0, stream, args);
+  } else if (args.cols <= 4096) {
+    hipLaunchKernelGGL((norm_fwd_kernel<2, LN, IT, ZK>), grid, block, 0, stream, args);
+  } else if (args.cols <= 8192) {
+    hipLaunchKernelGGL((norm_fwd_kernel<4, LN, IT, ZK>), grid, block, 0, stream, args);
+  } else {
+    hipLaunchKernelGGL((norm_fwd_kernel<8, LN, IT, ZK>), grid, block, 0, stream, args);
+  }
+}
+
+template <bool LN, typename IT>
+void launch_fwd_by_out(const NormFwdArgs &args, hipStream_t stream) {
+  if (args.z_dtype == kNVTEFloat8E4M3) launch_fwd_vec<LN, IT, kZE4M3>(args, stream);
+  else if (args.z_dtype == kNVTEFloat8E5M2) launch_fwd_vec<LN, IT, kZE5M2>(args, stream);
+  else launch_fwd_vec<LN, IT, kZSame>(args, stream);
+}
+
+// vec: shape / alignment allow the vector kernel; it also needs z to be FP8 or of x's dtype
 template <bool LN>
 void launch_fwd(const NormFwdArgs &args, bool vec, hipStream_t stream) {
-  const unsigned per_cu = !vec ? 8 : args.cols <= 2048 ? 8 : args.cols <= 4096 ? 6 : args.cols <= 8192 ? 4 : 2;
-  const dim3 grid(norm_grid(args.rows, per_cu)), block(256);
-  if (!vec) {
-    hipLaunchKernelGGL(norm_fwd_general_kernel<LN>, grid, block, 0, stream, args);
-  } else if (args.cols <= 2048) {
-    hipLaunchKernelGGL((norm_fwd_kernel<1, LN>), grid, block, 0, stream, args);
-  } else if (args.cols <= 4096) {
-    hipLaunchKernelGGL((norm_fwd_kernel<2, LN>), grid, block, 0, stream, args);
-  } else if (args.cols <= 8192) {
-    hipLaunchKernelGGL((norm_fwd_kernel<4, LN>), grid, block, 0, stream, args);
+  const bool z_fp8 = args.z_dtype == kNVTEFloat8E4M3 || args.z_dtype == kNVTEFloat8E5M2;
+  if (vec && (z_fp8 || args.z_dtype == args.x_dtype)) {
+    switch (args.x_dtype) {
+      case kNVTEBFloat16: launch_fwd_by_out<LN, bf16_t>(args, stream); break;
+      case kNVTEFloat16: launch_fwd_by_out<LN, f16_t>(args, stream); break;
+      default: launch_fwd_by_out<LN, float>(args, stream); break;
+    }
   } else {
-    hipLaunchKernelGGL((norm_fwd_kernel<8, LN>), grid, block, 0, stream, args);
+    hipLaunchKernelGGL(norm_fwd_general_kernel<LN>, dim3(norm_grid(args.rows, 8)), dim3(256), 0, stream, args);
   }
   NVTE_CHECK_HIP(hipGetLastError());
 }
 
+template <bool LN, typename IT>
+void launch_bwd_vec(const NormBwdArgs &args, unsigned nblocks, hipStream_t stream) {
+  const dim3 grid(nblocks), block(256);
+  if (args.cols <= 2048) {
+    hipLaunchKernelGGL((norm_bwd_kernel<1, LN, IT>), grid, block, 0, stream, args);
+  } else if (args.cols <= 4096) {
+    hipLaunchKernelGGL((norm_bwd_kernel<2, LN, IT>), grid, block, 0, stream, args);
+  } else {
+    hipLaunchKernelGGL((norm_bwd_kernel<4, LN, IT>), grid, block, 0, stream, args);
+  }
+}
+
+// vec additionally needs dz / add in x's dtype (w_dtype == x_dtype, the usual case)
 template <bool LN>
 void launch_bwd(const NormBwdArgs &args, unsigned nblocks, bool vec, hipStream_t stream) {
-  const dim3 grid(nblocks), block(256);
-  if (!vec) {
-    hipLaunchKernelGGL(norm_bwd_general_kernel<LN>, grid, block, 0, stream, args);
-  } else if (args.cols <= 2048) {
-    hipLaunchKernelGGL((norm_bwd_kernel<1, LN>), grid, block, 0, stream, args);
-  } else if (args.cols <= 4096) {
-    hipLaunchKernelGGL((norm_bwd_kernel<2, LN>), grid, block, 0, stream, args);
+  if (vec && args.w_dtype == args.x_dtype) {
+    switch (args.x_dtype) {
+      case kNVTEBFloat16: launch_bwd_vec<LN, bf16_t>(args, nblocks, stream); break;
+      case kNVTEFloat16: launch_bwd_vec<LN, f16_t>(args, nblocks, stream); break;
+      default: launch_bwd_vec<LN, float>(args, nblocks, stream); break;
+    }
   } else {
-    hipLaunchKernelGGL((norm_bwd_kernel<4, LN>), grid, block, 0, stream, args);
+    hipLaunchKernelGGL(norm_bwd_general_kernel<LN>, dim3(nblocks), dim3(256), 0, stream, args);
   }
   NVTE_CHECK_HIP(hipGetLastError());
 }
