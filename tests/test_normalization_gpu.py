@@ -142,3 +142,18 @@ def test_norm_argument_errors():
         rmsnorm_fwd(x, g[:32].contiguous(), 1e-5)
     with pytest.raises(NVTEError, match="Epsilon must be non-negative"):
         rmsnorm_fwd(x, g, -1.0)
+
+
+def test_norm_fwd_mixed_dtypes_take_the_general_kernel():
+    """bf16 input with fp32 output / fp32 gamma: not a vector-kernel combination, same numbers expected."""
+    N, H = 96, 1024
+    x, g, b = _inputs(N, H, torch.bfloat16, 21)
+    out32, _, rs = rmsnorm_fwd(x, g, 1e-5, out_dtype=torch.float32)
+    out_g32, mu, _ = layernorm_fwd(x, g.float(), b.float(), 1e-5)
+    torch.cuda.synchronize()
+    ref, _, rrs, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g), None, 1e-5)
+    assert out32.dtype == torch.float32
+    assert np.allclose(out32.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+    assert np.allclose(rs.cpu().numpy(), rrs, rtol=5e-5, atol=1e-6)
+    ref_ln, _, _, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g.float()), to_oracle_input(b.float()), 1e-5)
+    assert np.allclose(out_g32.float().cpu().numpy(), ref_ln, rtol=8e-3, atol=1e-5)
