@@ -141,7 +141,7 @@ def cpu_baseline(tokens=4096, K=4096, N=14336):
     elems = M * K + N * K + M * N
     return {
         "value": flops / total / 1e12, "unit": "TFLOP/s", "cores": oracle.num_threads(), "kind": "port",
-        "sample": f"configs[1] Linear {K}->{N} fwd+bwd on {M} of its 8192 tokens (full-size weight): "
+        "sample": f"Linear {K}->{N} fwd+bwd on {M} tokens (configs[1]: 4096 of its 8192 tokens, full-size weight): "
                   "3x cast_transpose+amax (serial reference loops, 1 core) + 3x dequantized-FP32 GEMM "
                   "(OpenMP, `cores` threads); dequantize-to-FP32 staging excluded",
         "cast_transpose_GBps": elems * 4 / (t1 - t0) / 1e9, "cast_transpose_cores": 1,
@@ -370,6 +370,26 @@ def main():
             result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+            # configs[0] (the reference's CPU-runnable case: Linear 768 -> 3072, 2048 tokens) in full, CPU and GPU
+            c1 = cpu_baseline(tokens=2048, K=768, N=3072)
+            x1 = torch.randn(2048, 768, device=dev, dtype=torch.bfloat16)
+            w1 = (torch.randn(3072, 768, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+            dy1 = (torch.randn(2048, 3072, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
+            st1 = L.LinearFP8State(recipe, device=dev)
+
+            def step1(first=False):
+                _, saved1 = L.linear_forward(x1, w1, None, st1, is_first_microbatch=first)
+                st1.update_fwd()
+                L.linear_backward(dy1, saved1, st1)
+                st1.update_bwd()
+
+            step1(first=True)
+            step1()
+            ms1 = time_kernel(step1, 20)
+            result["cpu_baseline"]["configs0_full"] = {
+                "workload": "configs[0]: Linear 768->3072, 2048 tokens, delayed scaling, fwd+bwd (28.99 GFLOP)",
+                "cpu_tflops": c1["value"], "cpu_seconds": c1["seconds"], "cpu_cores": c1["cores"],
+                "gpu_ms_per_step_eager": ms1, "gpu_tflops_eager": 6.0 * 2048 * 768 * 3072 / (ms1 * 1e-3) / 1e12}
 
     if rank == 0:
         print(json.dumps(result))
