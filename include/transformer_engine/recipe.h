@@ -39,6 +39,23 @@ void nvte_group_compute_amax_with_config(const NVTEGroupedTensor input, NVTEGrou
 void nvte_group_compute_scale_from_amax(NVTEGroupedTensor output, const NVTEQuantizationConfig config,
                                         hipStream_t stream);
 
+/* ref recipe.h:298 (common/recipe/mxfp8_scaling.cu:233).  `input` is the 1-D shard
+ * [start_offset, start_offset + len) of a row-major [rows, cols] master weight (rows, cols
+ * multiples of 32).  amax_rowwise [pad128(rows), pad4(cols/32)] and amax_colwise
+ * [pad4(rows/32), pad128(cols)], both of the input dtype, receive the maximum |x| of every 1x32 /
+ * 32x1 block over the elements the shard holds (0 for blocks it does not touch), ready for a MAX
+ * all-reduce over the data-parallel group. */
+void nvte_mxfp8_scaling_compute_partial_amax(const NVTETensor input, NVTETensor amax_rowwise,
+                                             NVTETensor amax_colwise, int rows, int cols,
+                                             size_t start_offset, hipStream_t stream);
+/* ref recipe.h:318 (mxfp8_scaling.cu:243).  Casts the shard to E4M3 twice, with the rowwise and
+ * the columnwise e8m0 decode scales of the FULL matrix (out = x * 2^(127 - e), saturating);
+ * outputs are 1-D byte shards of the same length as `input`. */
+void nvte_mxfp8_scaling_partial_cast(const NVTETensor input, NVTETensor output_rowwise,
+                                     NVTETensor output_colwise, const NVTETensor scale_inv_rowwise,
+                                     const NVTETensor scale_inv_colwise, int rows, int cols,
+                                     size_t start_offset, hipStream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 

@@ -108,6 +108,22 @@ def lib() -> ctypes.CDLL:
                                  c.c_size_t]
         L.te_colsum_ref.restype = None
         L.te_colsum_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_void_p]
+        L.te_mxfp8_partial_amax_ref.restype = None
+        L.te_mxfp8_partial_amax_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_size_t, c.c_size_t,
+                                                c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]
+        L.te_e8m0_from_amax_ref.restype = None
+        L.te_e8m0_from_amax_ref.argtypes = [c.c_void_p, c.c_size_t, c.c_void_p]
+        L.te_mxfp8_partial_cast_ref.restype = None
+        L.te_mxfp8_partial_cast_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_size_t, c.c_size_t, c.c_size_t,
+                                                c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t, c.c_void_p,
+                                                c.c_void_p]
+        L.te_scale_and_scale_inv_ref.restype = None
+        L.te_scale_and_scale_inv_ref.argtypes = [c.c_void_p, c.c_size_t, c.c_float, c.c_int, c.c_float, c.c_void_p,
+                                                 c.c_void_p]
+        L.te_adam_fp8_ref.restype = c.c_float
+        L.te_adam_fp8_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p,
+                                      c.c_void_p, c.c_float, c.c_int, c.c_float, c.c_float, c.c_float, c.c_float,
+                                      c.c_int, c.c_int, c.c_int, c.c_float]
         L.te_oracle_num_threads.restype = c.c_int
         _lib = L
     return _lib
@@ -339,6 +355,57 @@ def colsum(x: np.ndarray) -> np.ndarray:
     out = np.zeros(x.shape[-1], np.float32)
     lib().te_colsum_ref(_ptr(x), _in_dtype(x), rows, x.shape[-1], _ptr(out))
     return out
+
+
+# ---------------------------------------------------------------- FP8 weight-update path
+def mxfp8_partial_amax(shard: np.ndarray, rows: int, cols: int, start: int):
+    """Block amaxes of the shard [start, start+len) of a [rows, cols] matrix, in padded fp32 arrays
+    of the MXFP8 scale shapes (blocks the shard does not touch, and the padding, are 0)."""
+    shard = np.ascontiguousarray(shard).reshape(-1)
+    rs, cs = mxfp8_scale_shapes(rows, cols)
+    ar, ac = np.zeros(rs, np.float32), np.zeros(cs, np.float32)
+    lib().te_mxfp8_partial_amax_ref(_ptr(shard), _in_dtype(shard), shard.size, rows, cols, start, _ptr(ar),
+                                    rs[1], _ptr(ac), cs[1])
+    return ar, ac
+
+
+def e8m0_from_amax(amax: np.ndarray) -> np.ndarray:
+    amax = np.ascontiguousarray(amax, np.float32)
+    out = np.empty(amax.shape, np.uint8)
+    lib().te_e8m0_from_amax_ref(_ptr(amax), amax.size, _ptr(out))
+    return out
+
+
+def mxfp8_partial_cast(shard: np.ndarray, sc_row: np.ndarray, sc_col: np.ndarray, rows: int, cols: int,
+                       start: int):
+    shard = np.ascontiguousarray(shard).reshape(-1)
+    sc_row, sc_col = np.ascontiguousarray(sc_row, np.uint8), np.ascontiguousarray(sc_col, np.uint8)
+    out_r, out_c = np.empty(shard.size, np.uint8), np.empty(shard.size, np.uint8)
+    lib().te_mxfp8_partial_cast_ref(_ptr(shard), _in_dtype(shard), shard.size, rows, cols, start, _ptr(sc_row),
+                                    sc_row.shape[1], _ptr(sc_col), sc_col.shape[1], _ptr(out_r), _ptr(out_c))
+    return out_r, out_c
+
+
+def scale_and_scale_inv(amax: np.ndarray, fmt: int, force_pow_2: bool = False, epsilon: float = 0.0):
+    amax = np.ascontiguousarray(amax, np.float32)
+    scale, sinv = np.empty_like(amax), np.empty_like(amax)
+    lib().te_scale_and_scale_inv_ref(_ptr(amax), amax.size, ctypes.c_float(FP8_MAX[fmt]), int(force_pow_2),
+                                     ctypes.c_float(epsilon), _ptr(scale), _ptr(sinv))
+    return scale, sinv
+
+
+def adam_fp8(g: np.ndarray, p_master: np.ndarray, m: np.ndarray, v: np.ndarray, scale: float, fmt: int, *,
+             lr: float, beta1: float, beta2: float, eps: float, step: int, mode: int, bias_correction: int,
+             weight_decay: float):
+    """Returns (p_fp8 bytes, p_master, m, v, amax) after one Adam step on copies of the inputs."""
+    g = np.ascontiguousarray(g).reshape(-1)
+    pm, m, v = (np.array(a, np.float32, copy=True, order="C").reshape(-1) for a in (p_master, m, v))
+    p8 = np.empty(g.size, np.uint8)
+    f = ctypes.c_float
+    amax = lib().te_adam_fp8_ref(_ptr(g), _in_dtype(g), g.size, _ptr(pm), _ptr(m), _ptr(v), _ptr(p8), f(scale),
+                                 fmt, f(lr), f(beta1), f(beta2), f(eps), step, mode, bias_correction,
+                                 f(weight_decay))
+    return p8, pm, m, v, np.float32(amax)
 
 
 def float_to_bf16_bits(x: np.ndarray) -> np.ndarray:

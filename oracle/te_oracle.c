@@ -546,6 +546,101 @@ void te_act_ref(int mode, int id, const void *in, const void *grad, int dtype, f
     }
 }
 
+/* ---------------------------------------------------------------- FP8 weight-update path
+ * Shard ("partial") amax / cast of an MXFP8 master weight: restates the torch references the
+ * reference's own test holds, ref tests/pytorch/test_partial_cast.py:18-53
+ * (compute_partial_amax_reference: scatter the shard into a zero [h, w] matrix, |x|, max over
+ * 1x32 / 32x1 blocks; partial_cast_reference: x * 2^(127 - e) -> e4m3 with the rowwise and the
+ * columnwise block scale), kernels ref common/recipe/mxfp8_scaling.cu:26-131.
+ * amax arrays are fp32 here (the values are exact in the input dtype). */
+void te_mxfp8_partial_amax_ref(const void *in, int in_dtype, size_t len, size_t rows, size_t cols,
+                               size_t start, float *amax_row, size_t row_stride, float *amax_col,
+                               size_t col_stride) {
+  for (size_t r = 0; r < rows; ++r)
+    for (size_t cb = 0; cb < cols / 32; ++cb) amax_row[r * row_stride + cb] = 0.f;
+  for (size_t rb = 0; rb < rows / 32; ++rb)
+    for (size_t c = 0; c < cols; ++c) amax_col[rb * col_stride + c] = 0.f;
+  for (size_t i = 0; i < len; ++i) {
+    const size_t idx = start + i, r = idx / cols, c = idx % cols;
+    const float a = fabsf(load_in(in, i, in_dtype));
+    float *pr = &amax_row[r * row_stride + c / 32], *pc = &amax_col[(r / 32) * col_stride + c];
+    *pr = fmaxf(*pr, a);
+    *pc = fmaxf(*pc, a);
+  }
+}
+
+/* ref common/multi_tensor/compute_scale.cu:59-79: e = float_to_e8m0(amax * (1/448)); the
+ * reference's test restates it with a division, tests/pytorch/test_multi_tensor.py:398-406
+ * (the two agree on every bf16 amax: tests/test_oracle_weight_update.py). */
+void te_e8m0_from_amax_ref(const float *amax, size_t n, uint8_t *out) {
+  const float max_norm_rcp = 1.0f / 448.0f;
+  for (size_t i = 0; i < n; ++i) out[i] = te_float_to_e8m0(amax[i] * max_norm_rcp);
+}
+
+void te_mxfp8_partial_cast_ref(const void *in, int in_dtype, size_t len, size_t rows, size_t cols,
+                               size_t start, const uint8_t *sc_row, size_t row_stride,
+                               const uint8_t *sc_col, size_t col_stride, uint8_t *out_row,
+                               uint8_t *out_col) {
+  (void)rows;
+  for (size_t i = 0; i < len; ++i) {
+    const size_t idx = start + i, r = idx / cols, c = idx % cols;
+    const float x = load_in(in, i, in_dtype);
+    out_row[i] = te_float_to_fp8(x * te_exp2f_rcp(sc_row[r * row_stride + c / 32]), 0);
+    out_col[i] = te_float_to_fp8(x * te_exp2f_rcp(sc_col[(r / 32) * col_stride + c]), 0);
+  }
+}
+
+/* ref common/multi_tensor/compute_scale.cu:26-57 (+ recipe_common.cuh:14-49); the reference's
+ * test compares with scale_from_amax_tensor, rtol = atol = 0 (tests/pytorch/test_multi_tensor.py:
+ * 343-374). */
+void te_scale_and_scale_inv_ref(const float *amax, size_t n, float max_fp8, int force_pow_2, float eps,
+                                float *scale, float *scale_inv) {
+  for (size_t i = 0; i < n; ++i) {
+    scale[i] = te_scale_from_amax_ref(amax[i], max_fp8, force_pow_2, eps);
+    scale_inv[i] = 1.0f / scale[i];
+  }
+}
+
+/* ref common/multi_tensor/adam.cu:52-176 (AdamFunctorMaster with an FP8 PARAM_T) and :775-780
+ * (bias corrections).  Every operation rounds to fp32 on its own (this file is compiled with
+ * -ffp-contract=off, the HIP kernel with contraction off in the same function); the reference
+ * binary may fuse some multiply-adds, which moves results by at most an fp32 ulp per step.
+ * Returns max |p_master| after the update. */
+float te_adam_fp8_ref(const void *g, int g_dtype, size_t n, float *pm, float *m, float *v, uint8_t *p8,
+                      float scale, int fmt, float lr, float beta1, float beta2, float eps, int step,
+                      int mode, int bias_correction, float decay) {
+  float c1 = 1.f, c2 = 1.f;
+  if (bias_correction == 1) {
+    c1 = (float)(1 - pow((double)beta1, step));
+    c2 = (float)(1 - pow((double)beta2, step));
+  }
+  float amax = 0.f;
+  for (size_t i = 0; i < n; ++i) {
+    float rg = load_in(g, i, g_dtype), rp = pm[i], rm = m[i], rv = v[i];
+    if (mode == 0) {
+      rg = rg + (decay * rp);
+      rm = beta1 * rm + (1 - beta1) * rg;
+      rv = beta2 * rv + (1 - beta2) * rg * rg;
+      const float mh = rm / c1, vh = rv / c2;
+      const float denom = sqrtf(vh) + eps;
+      rp = rp - (lr * (mh / denom));
+    } else {
+      rm = beta1 * rm + (1 - beta1) * rg;
+      rv = beta2 * rv + (1 - beta2) * rg * rg;
+      const float mh = rm / c1, vh = rv / c2;
+      const float denom = sqrtf(vh) + eps;
+      const float upd = (mh / denom) + (decay * rp);
+      rp = rp - (lr * upd);
+    }
+    pm[i] = rp;
+    m[i] = rm;
+    v[i] = rv;
+    amax = fmaxf(amax, fabsf(rp));
+    p8[i] = te_float_to_fp8(rp * scale, fmt);
+  }
+  return amax;
+}
+
 int te_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

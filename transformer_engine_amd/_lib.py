@@ -224,6 +224,16 @@ _SIGS = {
     "nvte_cast_transpose_dbias_drelu": (_V, [_P, _P, _P, _P, _P, _P]),
     "nvte_cast_transpose_dbias_dqgelu": (_V, [_P, _P, _P, _P, _P, _P]),
     "nvte_cast_transpose_dbias_dsrelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    # multi_tensor.h + the shard (partial) cast of recipe.h: the FP8 weight-update path
+    "nvte_multi_tensor_scale_cuda": (_V, [_I, _P, C.POINTER(C.POINTER(_P)), _SZ, _SZ, _F, _P]),
+    "nvte_multi_tensor_scale_tensor_cuda": (_V, [_I, _P, C.POINTER(C.POINTER(_P)), _SZ, _SZ, _P, _P]),
+    "nvte_multi_tensor_compute_scale_and_scale_inv_cuda": (_V, [_I, _P, C.POINTER(C.POINTER(_P)), _SZ, _SZ,
+                                                                _F, _I, _F, _P]),
+    "nvte_multi_tensor_compute_scale_inv_e8m0_cuda": (_V, [_I, C.POINTER(C.POINTER(_P)), _SZ, _SZ, _P]),
+    "nvte_multi_tensor_adam_fp8_cuda": (_V, [_I, _P, C.POINTER(C.POINTER(_P)), _SZ, _SZ, _F, _F, _F, _F,
+                                             _I, _I, _I, _F, _I, _P]),
+    "nvte_mxfp8_scaling_compute_partial_amax": (_V, [_P, _P, _P, _I, _I, _SZ, _P]),
+    "nvte_mxfp8_scaling_partial_cast": (_V, [_P, _P, _P, _P, _P, _I, _I, _SZ, _P]),
     # swizzle.h
     "nvte_swizzle_scaling_factors": (_V, [_P, _P, _P]),
     "nvte_multi_tensor_swizzle_scaling_factors": (_V, [C.POINTER(_P), C.POINTER(_P), _SZ, _P]),
