@@ -11,6 +11,7 @@ Package layout (only what the path needs):
   grouped.py / grouped_linear.py  grouped (MoE) tensors, quantize and GEMM with device-side splits
   normalization.py  LayerNorm / RMSNorm with fused FP8 output (LayerNormLinear lives in linear.py)
   activation.py  plain / gated activations fused with the FP8 cast, transpose and dbias
+  weight_update.py  sharded master weights -> FP8 primary weights (multi-tensor kernels, MXFP8 shard cast)
 """
 from ._lib import NVTEError, api, version  # noqa: F401
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor,  # noqa: F401

@@ -231,7 +231,24 @@ __global__ __launch_bounds__(kMtThreads) void mt_e8m0_kernel(MtTable<2> t, int64
   const bf16_t *amax = static_cast<const bf16_t *>(t.addr[0][w.tensor]) + w.begin;
   uint8_t *scale_inv = static_cast<uint8_t *>(t.addr[1][w.tensor]) + w.begin;
   constexpr float max_norm_rcp = 1.0f / 448.0f;
-  for (int64_t i = threadIdx.x; i < w.len; i += kMtThreads)
+  int64_t done = 0;
+  if (((reinterpret_cast<uintptr_t>(amax) & 15) | (reinterpret_cast<uintptr_t>(scale_inv) & 7)) == 0) {
+    const int64_t nvec = w.len >> 3;  // 16 B of amaxes -> 8 B of exponents per lane
+    for (int64_t i = threadIdx.x; i < nvec; i += kMtThreads) {
+      const u32x4 raw = *reinterpret_cast<const u32x4 *>(amax + 8 * i);
+      uint32_t e[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e[2 * k] = float_to_e8m0(__uint_as_float(raw[k] << 16) * max_norm_rcp);
+        e[2 * k + 1] = float_to_e8m0(__uint_as_float(raw[k] & 0xFFFF0000u) * max_norm_rcp);
+      }
+      const u32x2 o = {e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24),
+                       e[4] | (e[5] << 8) | (e[6] << 16) | (e[7] << 24)};
+      *reinterpret_cast<u32x2 *>(scale_inv + 8 * i) = o;
+    }
+    done = nvec << 3;
+  }
+  for (int64_t i = done + threadIdx.x; i < w.len; i += kMtThreads)
     scale_inv[i] = float_to_e8m0(widen(amax[i]) * max_norm_rcp);
 }
 
