@@ -119,13 +119,100 @@ def test_quantize_dbias_uses_the_fused_pass_and_matches_oracle_bytes():
         assert np.allclose(dbias.float().cpu().numpy(), ref, rtol=2 ** -7, atol=2 ** -7 * np.abs(dy.float().cpu().numpy()).sum(axis=0).max())
 
 
-def test_activation_current_scaling_unfuses_and_mxfp8_is_rejected():
-    from transformer_engine_amd.tensor import MXFP8Quantizer
+def test_activation_current_scaling_unfuses():
     x = randn_input((128, 256), torch.bfloat16, 12)
     q = Float8CurrentScalingQuantizer(E4, torch.device("cuda"))
     out = activation("gelu", x, q)
     ref = q(activation("gelu", x))
     torch.cuda.synchronize()
     assert torch.equal(out._data, ref._data) and torch.equal(out._scale_inv, ref._scale_inv)
-    with pytest.raises(NotImplementedError):
-        activation("gelu", x, MXFP8Quantizer(E4))
+
+
+# ---------------------------------------------------------------- MXFP8 outputs (ref cast/mxfp8/gated_mxfp8.cuh,
+# quantize_mxfp8.cuh IS_ACT / IS_DACT; tests/cpp/operator/test_cast_mxfp8_gated_swiglu.cu, test_cast_mxfp8.cu)
+def _mx_quantizer(layout, fmt=E4):
+    from transformer_engine_amd.tensor import MXFP8Quantizer
+    q = MXFP8Quantizer(fmt, columnwise_transposed=(layout == "tcol"))
+    q.optimize_for_gemm = layout == "swizzled"
+    return q
+
+
+def _assert_same_mxfp8(a, b, rows, cols, layout):
+    """Payload and the scales of the valid region (compact layouts) / the whole arrays (swizzled: both
+    come from zero-initialised arrays of the same shape) must be identical."""
+    assert torch.equal(a._rowwise_data, b._rowwise_data)
+    assert torch.equal(a._columnwise_data, b._columnwise_data)
+    if layout == "swizzled":
+        assert torch.equal(a._rowwise_scale_inv, b._rowwise_scale_inv)
+        assert torch.equal(a._columnwise_scale_inv, b._columnwise_scale_inv)
+    else:
+        assert torch.equal(a._rowwise_scale_inv[:rows, :cols // 32], b._rowwise_scale_inv[:rows, :cols // 32])
+        if layout == "tcol":
+            assert torch.equal(a._columnwise_scale_inv[:cols, :rows // 32], b._columnwise_scale_inv[:cols, :rows // 32])
+        else:
+            assert torch.equal(a._columnwise_scale_inv[:rows // 32, :cols], b._columnwise_scale_inv[:rows // 32, :cols])
+
+
+@pytest.mark.parametrize("name", ["gelu", "srelu", "swiglu", "geglu", "glu"])
+@pytest.mark.parametrize("layout", ["compact", "tcol", "swizzled"])
+@pytest.mark.parametrize("N,H", [(256, 512), (384, 128), (96, 160)])      # whole tiles x2 / 32x32-tile path
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_activation_forward_mxfp8_equals_unfused(name, layout, N, H, dtype):
+    """The fused activation -> MXFP8 kernel must produce exactly what the unfused sequence does:
+    activation in the input dtype, then nvte_quantize (the reference rounds to IType before the block
+    quantize for that reason, gated_mxfp8.cuh:277-283)."""
+    if layout != "compact" and (N % 128 or H % 128):
+        pytest.skip("transposed / swizzled MXFP8 layouts need 128-multiples (as the plain quantize does)")
+    x = randn_input((N, 2 * H if name in GATED else H), dtype, 31) * 2
+    q = _mx_quantizer(layout)
+    out = activation(name, x, q)
+    ref = q(activation(name, x))
+    torch.cuda.synchronize()
+    _assert_same_mxfp8(out, ref, N, H, layout)
+    # and the unfused high-precision activation is the oracle-checked one (tests above)
+
+
+@pytest.mark.parametrize("name", ["gelu", "silu", "swiglu", "reglu", "qgeglu"])
+@pytest.mark.parametrize("layout", ["compact", "tcol"])
+@pytest.mark.parametrize("N,H", [(256, 512), (96, 160)])
+@pytest.mark.parametrize("fmt", [E4, E5])
+def test_activation_backward_mxfp8_equals_unfused(name, layout, N, H, fmt):
+    if layout != "compact" and (N % 128 or H % 128):
+        pytest.skip("transposed MXFP8 layout needs 128-multiples")
+    gated = name in GATED
+    x = randn_input((N, 2 * H if gated else H), torch.bfloat16, 32) * 2
+    g = randn_input((N, H), torch.bfloat16, 33)
+    q = _mx_quantizer(layout, fmt)
+    out = dactivation(name, g, x, q)
+    ref = q(dactivation(name, g, x))
+    torch.cuda.synchronize()
+    _assert_same_mxfp8(out, ref, N, 2 * H if gated else H, layout)
+
+
+@pytest.mark.parametrize("name", ["gelu", "relu"])
+@pytest.mark.parametrize("N,H", [(512, 768), (96, 160)])
+def test_dbias_dact_mxfp8(name, N, H):
+    x = randn_input((N, H), torch.bfloat16, 34) * 2
+    g = randn_input((N, H), torch.bfloat16, 35)
+    q = _mx_quantizer("compact")
+    dbias, out = dbias_dact(name, g, x, q)
+    ref_q = q(dactivation(name, g, x))
+    torch.cuda.synchronize()
+    _assert_same_mxfp8(out, ref_q, N, H, "compact")
+    ref = _ref(name, x, g)
+    want = ref.astype(np.float64).sum(axis=0)
+    assert np.allclose(dbias.float().cpu().numpy(), want, rtol=2 ** -7, atol=2 ** -7 * np.abs(ref).sum(axis=0).max())
+
+
+def test_quantize_dbias_mxfp8_fused_pass_equals_plain_quantize():
+    from transformer_engine_amd.linear import bgrad_quantize
+    for (N, H), layout in [((512, 768), "compact"), ((256, 384), "tcol"), ((96, 160), "compact")]:
+        dy = randn_input((N, H), torch.bfloat16, 36)
+        q = _mx_quantizer(layout)
+        dbias, out = bgrad_quantize(dy, q)
+        ref_q = q(dy)
+        torch.cuda.synchronize()
+        _assert_same_mxfp8(out, ref_q, N, H, layout)
+        ref = oracle.colsum(to_oracle_input(dy))
+        assert np.allclose(dbias.float().cpu().numpy(), ref, rtol=2 ** -7,
+                           atol=2 ** -7 * np.abs(dy.float().cpu().numpy()).sum(axis=0).max())

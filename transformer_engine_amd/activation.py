@@ -9,8 +9,8 @@ from typing import Optional
 import torch
 
 from ._lib import api
-from .tensor import (Float8CurrentScalingQuantizer, Float8Quantizer, TensorWrapper, current_stream_ptr,
-                     wrap_plain)
+from .tensor import (Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantizer, TensorWrapper,
+                     current_stream_ptr, wrap_plain)
 
 UNARY = ("gelu", "silu", "relu", "qgelu", "srelu")
 GATED = ("glu", "geglu", "swiglu", "reglu", "qgeglu", "sreglu")
@@ -30,8 +30,12 @@ def _make_out(shape, like: torch.Tensor, quantizer):
         w = quantizer._wrap_out(out)
         w.set_scale(quantizer.scale).set_amax(quantizer.amax)
         return out, w, None
+    if isinstance(quantizer, MXFP8Quantizer):
+        # block scales are local to the tile: the activation and the MXFP8 quantize are one kernel
+        out = quantizer.make_empty(shape, dtype=like.dtype, device=like.device)
+        return out, out.wrap(), None
     raise NotImplementedError(f"fused activation output for {type(quantizer).__name__} is not implemented "
-                              "(high precision or FP8 per-tensor scaling)")
+                              "(high precision, FP8 per-tensor scaling or MXFP8)")
 
 
 def _finish(out, hp, quantizer):

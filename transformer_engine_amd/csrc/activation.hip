@@ -36,7 +36,7 @@ namespace {
 
 enum : int { kActNone = 0, kActGelu, kActSilu, kActRelu, kActQGelu, kActSRelu, kActSigmoid };
 enum : int { kUnary = 0, kDAct = 1, kGatedFwd = 2, kGatedBwd = 3 };
-enum : int { kOutE4M3 = 0, kOutE5M2 = 1, kOutHP = 2 };
+enum : int { kOutE4M3 = 0, kOutE5M2 = 1, kOutHP = 2, kOutMXE4M3 = 3, kOutMXE5M2 = 4 };
 
 // exp through the hardware 2^x and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each): the library expf /
 // tanhf cost 20-40 instructions per value, which made gelu -> FP8 compute-bound (138 us against 82 us
@@ -103,7 +103,18 @@ struct FusedArgs {
   unsigned ld_in, ld_out;
   int in_dtype, out_dtype;
   int act;
+  // MXFP8 output (out_c = row-wise payload): column-wise payload, e8m0 scales and their layouts
+  uint8_t *mx_col, *sc_row, *sc_col;
+  unsigned stride_r, stride_c;  // second dims of the two scale arrays
+  int swz, tcol;                // GEMM-swizzled scales; column-wise payload stored transposed (amd_ext.h)
 };
+
+// compact -> GEMM-swizzled scale index (ref common/cast/mxfp8/swizzle.cuh:30-41; twin of mxfp8.hip)
+__device__ __forceinline__ size_t mx_swizzled_idx(size_t i, size_t j, size_t tiles_x) {
+  const size_t tile = (i / 128) * tiles_x + (j / 4);
+  const size_t y = i % 128, x = j % 4;
+  return tile * 512 + (y % 32) * 16 + (y / 32) * 4 + x;
+}
 
 constexpr int kTile = 128;
 
@@ -151,16 +162,110 @@ struct Raw8<float> {
   }
 };
 
+// MXFP8 block quantize of a thread's 8x8 values of output half `o` (ref cast/mxfp8/gated_mxfp8.cuh,
+// quantize_mxfp8.cuh; same thread map and arithmetic as mxfp8_tile_kernel in mxfp8.hip): a 1x32 row
+// block is 4 neighbouring lanes, a 32x1 column block the lanes {cg, cg+16, cg+32, cg+48} of a wave.
+// Whole 128x128 tiles only.  Which of the two directions, the scale layout and the transposed
+// column-wise store are block-uniform run-time choices around whole sections, not per element.
+template <Fp8 F>
+__device__ __forceinline__ void mx_store_block(float (&f)[8][8], const FusedArgs &a, unsigned t, size_t tile_r,
+                                               size_t tile_col, unsigned o, uint8_t *tile_t) {
+  constexpr float rcp_max = 1.0f / Fp8Traits<F>::max_finite;
+  const unsigned cg = t & 15u, rg = t >> 4;
+  const size_t row0 = tile_r * kTile + rg * 8;
+  const size_t ocol0 = static_cast<size_t>(o) * a.cols + tile_col * kTile + cg * 8;  // column of the output matrix
+  if (a.out_c) {
+    uint8_t *out_row = static_cast<uint8_t *>(a.out_c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, __builtin_fabsf(f[i][j]));
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
+      const uint8_t e = float_to_e8m0(m * rcp_max);
+      const float r = e8m0_rcp(e);
+      const u32x2 q = {cvt4_fp8<F>(f[i][0] * r, f[i][1] * r, f[i][2] * r, f[i][3] * r),
+                       cvt4_fp8<F>(f[i][4] * r, f[i][5] * r, f[i][6] * r, f[i][7] * r)};
+      *reinterpret_cast<u32x2 *>(out_row + (row0 + i) * a.ld_out + ocol0) = q;
+      const uint32_t e32 = e;
+      const uint32_t e1 = __shfl_down(e32, 4, 64), e2 = __shfl_down(e32, 8, 64), e3 = __shfl_down(e32, 12, 64);
+      if (cg == 0) {
+        const size_t r_idx = row0 + i, c_idx = (static_cast<size_t>(o) * a.cols + tile_col * kTile) / 32;
+        const size_t idx = a.swz ? mx_swizzled_idx(r_idx, c_idx, a.stride_r / 4) : r_idx * a.stride_r + c_idx;
+        *reinterpret_cast<uint32_t *>(a.sc_row + idx) = e32 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+      }
+    }
+  }
+  if (a.mx_col) {
+    uint32_t qc[8][2];
+    uint32_t ebytes[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float m = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m = fmaxf(m, __builtin_fabsf(f[i][j]));
+      m = fmaxf(m, __shfl_xor(m, 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const uint8_t e = float_to_e8m0(m * rcp_max);
+      ebytes[j >> 2] |= static_cast<uint32_t>(e) << (8 * (j & 3));
+      const float r = e8m0_rcp(e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i][j] *= r;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qc[i][0] = cvt4_fp8<F>(f[i][0], f[i][1], f[i][2], f[i][3]);
+      qc[i][1] = cvt4_fp8<F>(f[i][4], f[i][5], f[i][6], f[i][7]);
+      if (!a.tcol) {
+        const u32x2 q = {qc[i][0], qc[i][1]};
+        *reinterpret_cast<u32x2 *>(a.mx_col + (row0 + i) * a.ld_out + ocol0) = q;
+      }
+    }
+    if (a.tcol)
+      store_tile_transposed(tile_t, qc, t,
+                            a.mx_col + (static_cast<size_t>(o) * a.cols + tile_col * kTile) * a.rows + tile_r * kTile, a.rows);
+    if ((t & 63u) < 16u) {  // the wave's first row group holds the 32-row block scales of its 8 columns
+      const size_t blk = tile_r * 4 + (t >> 6);
+      if (a.swz) {
+        const size_t tiles_x = ceil_div_dev(a.rows, 128);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          a.sc_col[mx_swizzled_idx(ocol0 + j, blk, tiles_x)] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
+      } else if (a.tcol) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          a.sc_col[(ocol0 + j) * a.stride_c + blk] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
+      } else {
+        const u32x2 v = {ebytes[0], ebytes[1]};
+        *reinterpret_cast<u32x2 *>(a.sc_col + blk * a.stride_c + ocol0) = v;
+      }
+    }
+  }
+}
+
+template <typename IT>
+__device__ __forceinline__ float round_to_input_type(float v) {
+  if constexpr (std::is_same<IT, float>::value) {
+    return v;
+  } else {
+    IT o;
+    narrow(v, o);
+    return widen(o);
+  }
+}
+
 // ACT is a template parameter on purpose: dispatching on a run-time id inside the kernel (even once per
 // workgroup around seven inlined bodies) ends up as a branch tree PER ELEMENT after LLVM merges the
 // bodies back together - measured 103 us instead of 76 us for relu -> FP8 + transpose.
 template <typename IT, int OK, int MODE, int ACT, bool DBIAS>
 __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) {
-  constexpr bool FP8 = OK != kOutHP;
+  constexpr bool FP8 = OK == kOutE4M3 || OK == kOutE5M2;       // per-tensor scaling
+  constexpr bool MXO = OK == kOutMXE4M3 || OK == kOutMXE5M2;   // MXFP8 block scaling (whole tiles only)
   constexpr int NOUT = MODE == kGatedBwd ? 2 : 1;
   constexpr bool GATED = MODE == kGatedFwd || MODE == kGatedBwd;
   constexpr bool GRAD = MODE == kDAct || MODE == kGatedBwd;
-  __shared__ __attribute__((aligned(16))) uint8_t tile_t[FP8 ? kTile * kTile : 16];
+  __shared__ __attribute__((aligned(16))) uint8_t tile_t[(FP8 || MXO) ? kTile * kTile : 16];
   __shared__ float colpart[DBIAS ? 16 : 1][kTile];
   __shared__ float red[4];
   const unsigned t = threadIdx.x, cg = t & 15u, rg = t >> 4;
@@ -172,16 +277,58 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
   const float scale = (FP8 && a.scale) ? *a.scale : 1.f;
   const IT *in = static_cast<const IT *>(a.in), *grad = static_cast<const IT *>(a.grad);
   Raw8<IT> r0[8], r1[GATED ? 8 : 1], rg8[GRAD ? 8 : 1];
+  auto load_tile = [&] {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const size_t r = min(row0 + i, static_cast<size_t>(a.rows - 1));
-    r0[i].load(in + r * a.ld_in + col_ld);
-    if constexpr (GATED) r1[i].load(in + r * a.ld_in + a.cols + col_ld);
-    if constexpr (GRAD) rg8[i].load(grad + r * a.cols + col_ld);
-  }
+    for (int i = 0; i < 8; ++i) {
+      const size_t r = min(row0 + i, static_cast<size_t>(a.rows - 1));
+      r0[i].load(in + r * a.ld_in + col_ld);
+      if constexpr (GATED) r1[i].load(in + r * a.ld_in + a.cols + col_ld);
+      if constexpr (GRAD) rg8[i].load(grad + r * a.cols + col_ld);
+    }
+  };
+  if constexpr (!MXO) load_tile();
   float amax = 0.f;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  uint32_t q[NOUT][8][2];
+  uint32_t q[NOUT][FP8 ? 8 : 1][2];
+  if constexpr (MXO) {
+    // One output half at a time (the gated backward has two): the thread's 8x8 block of fp32 values must
+    // be complete before its block scales exist, and with both halves unrolled into one body the
+    // compiler keeps 270-370 VGPRs alive (one wave per SIMD: measured 485 us for dswiglu against 427 us
+    // unfused).  So the halves are iterations of a REAL loop: the second one reloads the tile (L2-hot)
+    // and picks its value with a select - both candidates share the sigmoid.
+#pragma unroll 1
+    for (int o = 0; o < NOUT; ++o) {
+      load_tile();
+      float f[8][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float x0[8], x1[8], g[8];
+        r0[i].unpack(x0);
+        if constexpr (GATED) r1[i].unpack(x1);
+        if constexpr (GRAD) rg8[i].unpack(g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float v;
+          if constexpr (MODE == kUnary) v = act_c<ACT>(x0[k]);
+          if constexpr (MODE == kDAct) v = g[k] * dact_c<ACT>(x0[k]);
+          if constexpr (MODE == kGatedFwd) v = act_c<ACT>(x0[k]) * x1[k];
+          if constexpr (MODE == kGatedBwd) {
+            const float va = dact_c<ACT>(x0[k]) * g[k] * x1[k];
+            const float vg = g[k] * act_c<ACT>(x0[k]);
+            v = o == 0 ? va : vg;
+          }
+          if constexpr (DBIAS) cs[k] += v;  // NOUT == 1 whenever DBIAS
+          // the block quantize sees the value rounded to the input dtype, i.e. what the unfused
+          // activation -> quantize sequence would read back (ref gated_mxfp8.cuh:277-283,
+          // quantize_mxfp8.cuh:244-247; the dbias sum takes the unrounded value, as there)
+          f[i][k] = round_to_input_type<IT>(v);
+          amax = fmaxf(amax, __builtin_fabsf(f[i][k]));
+        }
+      }
+      if (o && a.tcol) __syncthreads();  // the LDS image is reused
+      mx_store_block<OK == kOutMXE4M3 ? Fp8::E4M3 : Fp8::E5M2>(f, a, t, tile_r, tile_col, o, tile_t);
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const size_t r = row0 + i;
@@ -220,6 +367,7 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
         if (ok) store8(a.out_c, r * a.ld_out + o * a.cols + col0, a.out_dtype, v[o]);
       }
     }
+  }
   }
   if constexpr (FP8) {
     if (a.out_t) {
@@ -289,6 +437,91 @@ __global__ __launch_bounds__(256) void fused_act_general_kernel(const FusedArgs 
     if (threadIdx.x == 0) atomic_max_nonneg(a.amax, amax);
   }
   if (fp8 && blockIdx.x == 0 && threadIdx.x == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
+}
+
+// MXFP8 output for any shape: one 32x32 tile of the OUTPUT matrix per workgroup (the structure of
+// mxfp8_general_kernel in mxfp8.hip), value by value with every choice at run time.
+template <Fp8 F>
+__global__ __launch_bounds__(256) void fused_act_mx_general_kernel(const FusedArgs a, const int mode) {
+  __shared__ float tile[32][33];
+  __shared__ float col_rcp[32];
+  __shared__ float red[4];
+  constexpr float rcp_max = 1.0f / Fp8Traits<F>::max_finite;
+  const unsigned t = threadIdx.x, tx = t & 31u, ty = t >> 5;
+  const size_t out_cols = a.ld_out;
+  const size_t tiles_c = ceil_div_dev(out_cols, 32);
+  const size_t tile_y = blockIdx.x / tiles_c, tile_x = blockIdx.x % tiles_c;
+  const size_t r0 = tile_y * 32, c0 = tile_x * 32;
+  float tmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const size_t r = r0 + ty + 8 * i, co = c0 + tx;
+    float v = 0.f;
+    if (r < a.rows && co < out_cols) {
+      const size_t o = co / a.cols, c = co % a.cols;  // o = 1: the gate half of a gated backward
+      const float x0 = load1(a.in, r * a.ld_in + c, a.in_dtype);
+      const float x1 = (mode == kGatedFwd || mode == kGatedBwd) ? load1(a.in, r * a.ld_in + a.cols + c, a.in_dtype) : 0.f;
+      const float g = (mode == kDAct || mode == kGatedBwd) ? load1(a.grad, r * a.cols + c, a.in_dtype) : 0.f;
+      switch (mode) {
+        case kUnary: v = act_f(a.act, x0); break;
+        case kDAct: v = g * dact_f(a.act, x0); break;
+        case kGatedFwd: v = act_f(a.act, x0) * x1; break;
+        default: v = o == 0 ? dact_f(a.act, x0) * g * x1 : g * act_f(a.act, x0); break;
+      }
+      if (a.dbias_part) atomicAdd(a.dbias_part + c, v);
+      v = round_to(v, a.in_dtype);
+    }
+    tile[ty + 8 * i][tx] = v;
+    tmax = fmaxf(tmax, __builtin_fabsf(v));
+  }
+  __syncthreads();
+  if (a.out_c != nullptr) {
+    uint8_t *out_row = static_cast<uint8_t *>(a.out_c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lr = ty + 8 * i;
+      const size_t r = r0 + lr, c = c0 + tx;
+      const float x = tile[lr][tx];
+      float m = __builtin_fabsf(x);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+      const uint8_t e = float_to_e8m0(m * rcp_max);
+      if (r < a.rows && c < out_cols) out_row[r * out_cols + c] = cvt1_fp8<F>(x * e8m0_rcp(e));
+      if (tx == 0 && r < a.rows) {
+        const size_t idx = a.swz ? mx_swizzled_idx(r, tile_x, ceil_div_dev(out_cols, 128)) : r * a.stride_r + tile_x;
+        a.sc_row[idx] = e;
+      }
+    }
+  }
+  if (a.mx_col != nullptr) {
+    if (t < 32) {
+      float m = 0.f;
+      for (int i = 0; i < 32; ++i) m = fmaxf(m, __builtin_fabsf(tile[i][t]));
+      const uint8_t e = float_to_e8m0(m * rcp_max);
+      col_rcp[t] = e8m0_rcp(e);
+      const size_t c = c0 + t;
+      if (c < out_cols) {
+        const size_t idx = a.swz ? mx_swizzled_idx(c, tile_y, ceil_div_dev(a.rows, 128))
+                                 : (a.tcol ? c * a.stride_c + tile_y : tile_y * a.stride_c + c);
+        a.sc_col[idx] = e;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lr = ty + 8 * i;
+      const size_t r = r0 + lr, c = c0 + tx;
+      if (r < a.rows && c < out_cols) {
+        const uint8_t q = cvt1_fp8<F>(tile[lr][tx] * col_rcp[tx]);
+        if (a.tcol) a.mx_col[c * a.rows + r] = q;
+        else a.mx_col[r * out_cols + c] = q;
+      }
+    }
+  }
+  if (a.amax) {
+    tmax = block_max<4>(tmax, red);
+    if (t == 0) atomic_max_nonneg(a.amax, tmax);
+  }
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -376,10 +609,83 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
                "Workspace is too small (need ", ceil_div(rows, kSlab) * H, " fp32 entries)");
   }
   check_output(out, "output");
-  NVTE_CHECK(is_tensor_scaling(out.scaling_mode),
-             "fused activation + cast: only high-precision and FP8 per-tensor-scaling outputs are implemented, got ",
+  NVTE_CHECK(is_tensor_scaling(out.scaling_mode) || is_mxfp8(out.scaling_mode),
+             "fused activation + cast: high-precision, FP8 per-tensor-scaling and MXFP8 outputs are implemented, got ",
              scaling_mode_name(out.scaling_mode));
   const DType odt = out.dtype();
+  if (is_mxfp8(out.scaling_mode)) {
+    NVTE_CHECK(is_fp8(odt), "MXFP8 output needs an FP8 dtype, got ", dtype_name(odt));
+    NVTE_CHECK(out.has_data() || out.has_columnwise_data(), "Output is not allocated");
+    NVTE_CHECK(rows < (1ull << 31) && out_cols < (1ull << 31), "tensor too large");
+    FusedArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in.data.ptr;
+    a.grad = grad ? grad->data.ptr : nullptr;
+    a.dbias_part = dbias ? static_cast<float *>(workspace->data.ptr) : nullptr;
+    a.amax = static_cast<float *>(out.amax.ptr);
+    a.rows = static_cast<unsigned>(rows);
+    a.cols = static_cast<unsigned>(H);
+    a.ld_in = static_cast<unsigned>(in.cols());
+    a.ld_out = static_cast<unsigned>(out_cols);
+    a.in_dtype = in.data.dtype;
+    a.out_dtype = odt;
+    a.act = act;
+    a.swz = out.with_gemm_swizzled_scales ? 1 : 0;
+    a.tcol = out.columnwise_transposed ? 1 : 0;
+    if (out.has_data()) {
+      NVTE_CHECK(out.data.numel() == rows * out_cols, "Output has wrong size (expected ", rows, "x", out_cols, ")");
+      NVTE_CHECK(out.scale_inv.ptr != nullptr && out.scale_inv.shape.ndim == 2 &&
+                     out.scale_inv.shape.data[0] >= rows && out.scale_inv.shape.data[1] >= ceil_div(out_cols, 32),
+                 "Row-wise scale_inv of the MXFP8 output is missing or too small");
+      a.out_c = out.data.ptr;
+      a.sc_row = static_cast<uint8_t *>(out.scale_inv.ptr);
+      a.stride_r = static_cast<unsigned>(out.scale_inv.shape.data[1]);
+    }
+    if (out.has_columnwise_data()) {
+      NVTE_CHECK(out.columnwise_data.numel() == rows * out_cols, "Column-wise output has wrong size");
+      const NVTEShape &cs = out.columnwise_scale_inv.shape;
+      NVTE_CHECK(out.columnwise_scale_inv.ptr != nullptr && cs.ndim == 2, "Column-wise scale_inv of the MXFP8 output is missing");
+      if (a.tcol)
+        NVTE_CHECK(cs.data[0] >= out_cols && cs.data[1] >= ceil_div(rows, 32), "Column-wise scale_inv is too small");
+      else
+        NVTE_CHECK(cs.data[0] >= ceil_div(rows, 32) && cs.data[1] >= out_cols, "Column-wise scale_inv is too small");
+      a.mx_col = static_cast<uint8_t *>(out.columnwise_data.ptr);
+      a.sc_col = static_cast<uint8_t *>(out.columnwise_scale_inv.ptr);
+      a.stride_c = static_cast<unsigned>(cs.data[1]);
+    }
+    if (a.swz) {
+      // the swizzled layout addresses whole 128 x 4 scale tiles: the arrays must be padded as the reference pads them
+      if (a.sc_row) NVTE_CHECK(out.scale_inv.shape.data[0] % 128 == 0 && a.stride_r % 4 == 0, "swizzled row-wise scales need (128, 4) padding");
+      if (a.sc_col) NVTE_CHECK(out.columnwise_scale_inv.numel() >= round_up(out_cols, 128) * round_up(ceil_div(rows, 32), 4),
+                               "swizzled column-wise scales need (128, 4) padding");
+    }
+    if (rows == 0 || H == 0) return;
+    (void)device_info();
+    if (a.amax) NVTE_CHECK_HIP(hipMemsetAsync(a.amax, 0, sizeof(float), stream));
+    const size_t slabs = ceil_div(rows, kSlab);
+    const bool whole = rows % kTile == 0 && H % kTile == 0 && aligned16(a.in) && (!a.grad || aligned16(a.grad)) &&
+                       (!a.out_c || aligned16(a.out_c)) && (!a.mx_col || aligned16(a.mx_col)) &&
+                       (!a.sc_row || (reinterpret_cast<uintptr_t>(a.sc_row) & 3u) == 0) &&
+                       (!a.sc_col || (reinterpret_cast<uintptr_t>(a.sc_col) & 7u) == 0) &&
+                       (a.stride_r % 4 == 0) && (a.tcol || a.swz || a.stride_c % 8 == 0);
+    if (whole) {
+      const size_t tiles = slabs * (H / kTile);
+      NVTE_CHECK(tiles < (1ull << 31), "tensor too large");
+      if (odt == kNVTEFloat8E4M3) launch_tile_by_input<kOutMXE4M3>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
+      else launch_tile_by_input<kOutMXE5M2>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
+    } else {
+      if (dbias) NVTE_CHECK_HIP(hipMemsetAsync(a.dbias_part, 0, slabs * H * sizeof(float), stream));
+      const size_t tiles = ceil_div(rows, 32) * ceil_div(out_cols, 32);
+      NVTE_CHECK(tiles < (1ull << 31), "tensor too large");
+      if (odt == kNVTEFloat8E4M3)
+        hipLaunchKernelGGL(fused_act_mx_general_kernel<Fp8::E4M3>, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, stream, a, mode);
+      else
+        hipLaunchKernelGGL(fused_act_mx_general_kernel<Fp8::E5M2>, dim3(static_cast<unsigned>(tiles)), dim3(256), 0, stream, a, mode);
+    }
+    NVTE_CHECK_HIP(hipGetLastError());
+    if (dbias) dbias_finalize_launch(a.dbias_part, *dbias, slabs, H, stream);
+    return;
+  }
   const bool fp8 = is_fp8(odt);
   NVTE_CHECK(fp8 || is_high_precision(odt), "Unsupported output dtype ", dtype_name(odt));
   NVTE_CHECK(fp8 || out.has_data(), "High-precision output needs row-wise data");

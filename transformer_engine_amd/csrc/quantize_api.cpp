@@ -16,11 +16,13 @@ namespace te {
 
 bool dbias_workspace_query(const Tensor &in, Tensor &workspace);                             // dbias.hip
 void dbias_launch(const Tensor &in, Tensor &dbias, Tensor &workspace, hipStream_t stream);   // dbias.hip
-// activation.hip: cast (+transpose) and the column sums in ONE pass, FP8 per-tensor-scaling outputs
+// activation.hip: cast (+transpose) and the column sums in ONE pass, FP8 per-tensor-scaling and MXFP8 outputs
 void fused_cast_dbias_launch(const Tensor &in, Tensor &out, Tensor &dbias, Tensor &workspace, hipStream_t stream);
 static bool fused_dbias_ok(const Tensor &in, const Tensor &out) {
-  return is_tensor_scaling(out.scaling_mode) && is_fp8(out.dtype()) && out.has_data() &&
-         is_high_precision(in.data.dtype);
+  if (!is_fp8(out.dtype()) || !is_high_precision(in.data.dtype)) return false;
+  if (is_tensor_scaling(out.scaling_mode)) return out.has_data();
+  // MXFP8: whole 128x128 tiles take the fused tile kernel (other shapes keep the two-pass route)
+  return is_mxfp8(out.scaling_mode) && in.rows() % 128 == 0 && in.cols() % 128 == 0 && in.data.numel() > 0;
 }
 
 // The OUTPUT tensor's format picks the kernel (ref dispatch/quantize.cuh:63-93).
