@@ -218,6 +218,38 @@ def main():
 
     use_graph = (not args.no_graph) and world == 1   # RCCL collectives are left out of graph capture
     graph = None
+    seg = None
+    if (not args.no_graph) and world > 1 and args.parallelism == "dp":
+        # N data-parallel replicas: the same kernels as at N = 1, replayed from TWO graphs (forward,
+        # backward) with the recipe's packed amax all_reduce(MAX) + scale update issued eagerly between
+        # them - no collective is ever captured.
+        try:
+            holder = {}
+
+            def fwd_part():
+                holder["y"], holder["saved"] = L.linear_forward(x, w, None, st, is_first_microbatch=False)
+
+            def bwd_part():
+                holder["dx"], holder["dw"], _ = L.linear_backward(dy, holder["saved"], st)
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fwd_part(); st.update_fwd(); bwd_part(); st.update_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_fwd):
+                fwd_part()
+            with torch.cuda.graph(g_bwd, pool=g_fwd.pool()):
+                bwd_part()
+            torch.cuda.synchronize()
+            seg = (g_fwd, g_bwd)
+        except Exception as exc:
+            print(f"[bench] hipGraph capture unavailable ({type(exc).__name__}: {exc}); running eagerly",
+                  file=sys.stderr)
+            seg = None
+            torch.cuda.synchronize()
     if use_graph:
         try:
             side = torch.cuda.Stream()
@@ -236,7 +268,13 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
-    run = (lambda: graph.replay()) if graph is not None else (lambda: step())
+    def run_segments():
+        seg[0].replay()
+        st.update_fwd()
+        seg[1].replay()
+        st.update_bwd()
+
+    run = (lambda: graph.replay()) if graph is not None else (run_segments if seg is not None else (lambda: step()))
 
     for _ in range(args.warmup):
         run()
@@ -267,7 +305,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Llama-3-8B MLP Linear 4096->14336, FP8 delayed scaling "
                                "(HYBRID), fwd+bwd, 8192 tokens per GPU",
                    "tokens": global_tokens, "in_features": K, "out_features": N, "parallelism": parallelism,
-                   "hip_graph": graph is not None, "weight_quantize": "amortised (is_first_microbatch=False)"},
+                   "hip_graph": graph is not None or seg is not None, "weight_quantize": "amortised (is_first_microbatch=False)"},
         "tflops_per_gpu": tflops / world,
     }
 
