@@ -78,3 +78,42 @@ def grouped_linear_backward(dy: torch.Tensor, saved, first_dims: torch.Tensor, s
         accumulate_wgrad = False
     general_grouped_gemm_for_grouped_tensor(x8, dy8, wgrad_out, layout="NT", accumulate=accumulate_wgrad)
     return dx.rowwise_data.view(dy.shape[0], K), wgrad_out
+
+
+class _GroupedLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, first_dims, module):
+        y, saved = grouped_linear_forward(x, weight, first_dims, module.fp8_state,
+                                          is_first_microbatch=module._is_first_microbatch,
+                                          needs_backward=module._needs_backward)
+        ctx.saved_q, ctx.first_dims, ctx.module = saved, first_dims, module
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m = ctx.module
+        dx, dws = grouped_linear_backward(dy, ctx.saved_q, ctx.first_dims, m.fp8_state)
+        return dx, torch.cat(dws, dim=0), None, None
+
+
+class GroupedLinear(torch.nn.Module):
+    """``te.GroupedLinear`` look-alike (ref pytorch/module/grouped_linear.py): ``num_gemms`` experts of
+    [out_features, in_features] stacked in ONE parameter; ``forward(x, m_splits)`` takes the rows of x
+    sorted by expert and the split sizes as an int64 DEVICE tensor (they are never read on the host)."""
+
+    def __init__(self, num_gemms: int, in_features: int, out_features: int,
+                 params_dtype: torch.dtype = torch.bfloat16, device="cuda", recipe=None):
+        super().__init__()
+        self.num_gemms, self.in_features, self.out_features = num_gemms, in_features, out_features
+        self.weight = torch.nn.Parameter(torch.empty(num_gemms * out_features, in_features, dtype=params_dtype,
+                                                     device=device))
+        torch.nn.init.normal_(self.weight, std=0.02)
+        self.fp8_state = GroupedLinearFP8State(recipe or Float8CurrentScaling(), num_gemms, device=torch.device(device))
+        self._is_first_microbatch = None
+
+    def forward(self, x: torch.Tensor, m_splits: torch.Tensor, is_first_microbatch: Optional[bool] = None):
+        if not (isinstance(m_splits, torch.Tensor) and m_splits.is_cuda and m_splits.dtype == torch.int64):
+            raise TypeError("m_splits must be an int64 tensor on the GPU (the grouped path never syncs with the host)")
+        self._is_first_microbatch = is_first_microbatch
+        self._needs_backward = torch.is_grad_enabled()
+        return _GroupedLinearFn.apply(x, self.weight, m_splits, self)

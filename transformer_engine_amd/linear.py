@@ -205,7 +205,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, module):
         st = module.fp8_state
         y, saved = linear_forward(x, weight, bias, st, is_first_microbatch=module._is_first_microbatch,
-                                  needs_backward=torch.is_grad_enabled())
+                                  needs_backward=module._needs_backward)   # grad mode is off inside forward()
         ctx.saved_q = saved
         ctx.module = module
         ctx.use_bias = bias is not None
@@ -248,8 +248,64 @@ class Linear(torch.nn.Module):
 
     def forward(self, x: torch.Tensor, is_first_microbatch: Optional[bool] = None) -> torch.Tensor:
         self._is_first_microbatch = is_first_microbatch
+        self._needs_backward = torch.is_grad_enabled()
         y = _LinearFn.apply(x, self.weight, self.bias, self)
         # the reference runs the forward recipe step when the autocast region exits
         # (quantization.py:762); one module == one region here
+        self.fp8_state.update_fwd(self.amax_group)
+        return y
+
+
+class _LayerNormLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_weight, ln_bias, weight, bias, module):
+        y, saved = layernorm_linear_forward(
+            x, ln_weight, ln_bias, weight, bias, module.fp8_state, eps=module.eps,
+            normalization=module.normalization, zero_centered_gamma=module.zero_centered_gamma,
+            is_first_microbatch=module._is_first_microbatch, needs_backward=module._needs_backward)
+        ctx.saved_q = saved
+        ctx.module = module
+        ctx.ln_weight = ln_weight
+        ctx.use_bias = bias is not None
+        ctx.x_shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m = ctx.module
+        dx, dgamma, dbeta, dw, dbias = layernorm_linear_backward(
+            dy, ctx.saved_q, ctx.ln_weight, m.fp8_state, normalization=m.normalization,
+            zero_centered_gamma=m.zero_centered_gamma, use_bias=ctx.use_bias)
+        m.fp8_state.update_bwd(m.amax_group)
+        return dx.reshape(ctx.x_shape), dgamma, dbeta, dw, dbias, None
+
+
+class LayerNormLinear(torch.nn.Module):
+    """``te.LayerNormLinear`` look-alike for one GPU (ref pytorch/module/layernorm_linear.py): LayerNorm /
+    RMSNorm whose output is written as the GEMM's FP8 operand, then the FP8 Linear."""
+
+    def __init__(self, in_features: int, out_features: int, eps: float = 1e-5, bias: bool = True,
+                 normalization: str = "LayerNorm", zero_centered_gamma: bool = False,
+                 params_dtype: torch.dtype = torch.bfloat16, device="cuda", recipe=None):
+        super().__init__()
+        if normalization not in ("LayerNorm", "RMSNorm"):
+            raise ValueError(f"unsupported normalization {normalization}")
+        self.in_features, self.out_features, self.eps = in_features, out_features, eps
+        self.normalization, self.zero_centered_gamma = normalization, zero_centered_gamma
+        g0 = torch.zeros if zero_centered_gamma else torch.ones
+        self.layer_norm_weight = torch.nn.Parameter(g0(in_features, dtype=params_dtype, device=device))
+        self.layer_norm_bias = (torch.nn.Parameter(torch.zeros(in_features, dtype=params_dtype, device=device))
+                                if normalization == "LayerNorm" else None)
+        self.weight = torch.nn.Parameter(torch.empty(out_features, in_features, dtype=params_dtype, device=device))
+        torch.nn.init.normal_(self.weight, std=0.02)
+        self.bias = torch.nn.Parameter(torch.zeros(out_features, dtype=params_dtype, device=device)) if bias else None
+        self.fp8_state = LinearFP8State(recipe or DelayedScaling(), device=torch.device(device))
+        self._is_first_microbatch = None
+        self.amax_group = None
+
+    def forward(self, x: torch.Tensor, is_first_microbatch: Optional[bool] = None) -> torch.Tensor:
+        self._is_first_microbatch = is_first_microbatch
+        self._needs_backward = torch.is_grad_enabled()
+        y = _LayerNormLinearFn.apply(x, self.layer_norm_weight, self.layer_norm_bias, self.weight, self.bias, self)
         self.fp8_state.update_fwd(self.amax_group)
         return y
