@@ -43,6 +43,21 @@ void nvte_dreglu(const NVTETensor grad, const NVTETensor input, NVTETensor outpu
 void nvte_dqgeglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
 void nvte_dsreglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, hipStream_t stream);
 
+/* ref activation.h:346-370.  out[N, H] = act(in[:, :H]) * (clamp(in[:, H:], -limit, limit) + glu_linear_offset)
+ * with act(x) = c * sigmoid(alpha * c), c = min(x, limit) (GPT-OSS).  The form without the offset is the
+ * reference's deprecated one (offset 1).  Outputs as the other gated activations (high precision,
+ * FP8 per-tensor scaling with transpose, MXFP8). */
+void nvte_clamped_swiglu(const NVTETensor input, NVTETensor output, float limit, float alpha,
+                         hipStream_t stream);
+void nvte_clamped_swiglu_v2(const NVTETensor input, NVTETensor output, float limit, float alpha,
+                            float glu_linear_offset, hipStream_t stream);
+/* ref activation.h:487-512.  out[N, 2H]: [:, :H] = grad * act'(a) * (clamp(g) + offset) with act' = 0 for
+ * a > limit; [:, H:] = grad * act(a) where |g| <= limit, else 0. */
+void nvte_clamped_dswiglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, float limit,
+                          float alpha, hipStream_t stream);
+void nvte_clamped_dswiglu_v2(const NVTETensor grad, const NVTETensor input, NVTETensor output, float limit,
+                             float alpha, float glu_linear_offset, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,9 @@ def lib() -> ctypes.CDLL:
         L.te_adam_fp8_ref.argtypes = [c.c_void_p, c.c_int, c.c_size_t, c.c_void_p, c.c_void_p, c.c_void_p,
                                       c.c_void_p, c.c_float, c.c_int, c.c_float, c.c_float, c.c_float, c.c_float,
                                       c.c_int, c.c_int, c.c_int, c.c_float]
+        L.te_clamped_swiglu_ref.restype = None
+        L.te_clamped_swiglu_ref.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t,
+                                            c.c_size_t, c.c_float, c.c_float, c.c_float]
         L.te_oracle_num_threads.restype = c.c_int
         _lib = L
     return _lib
@@ -346,6 +349,18 @@ def activation(mode: str, act: str, x: np.ndarray, grad=None) -> np.ndarray:
     g = np.ascontiguousarray(grad) if grad is not None else None
     lib().te_act_ref(ACT_MODES[mode], ACT_IDS[act], _ptr(x), _ptr(g) if g is not None else None, _in_dtype(x),
                      _ptr(out), R, H)
+    return out
+
+
+def clamped_swiglu(x: np.ndarray, grad=None, *, limit: float, alpha: float, offset: float = 1.0) -> np.ndarray:
+    """x [R, 2H] (activation half first); grad None -> forward [R, H], else backward [R, 2H] (fp32)."""
+    x = np.ascontiguousarray(x)
+    R, H = x.shape[0], x.shape[1] // 2
+    out = np.empty((R, H if grad is None else 2 * H), np.float32)
+    g = None if grad is None else np.ascontiguousarray(grad)
+    f = ctypes.c_float
+    lib().te_clamped_swiglu_ref(0 if grad is None else 1, _ptr(x), _ptr(g), _in_dtype(x), _ptr(out), R, H, f(limit),
+                                f(alpha), f(offset))
     return out
 
 

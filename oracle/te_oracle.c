@@ -641,6 +641,33 @@ float te_adam_fp8_ref(const void *g, int g_dtype, size_t n, float *pm, float *m,
   return amax;
 }
 
+/* ---------------------------------------------------------------- clamped SwiGLU (GPT-OSS)
+ * ref common/util/math.h:80-98 (clamped_silu, clamped_dsilu = qgelu_with_alpha / dqgelu_with_alpha of the
+ * clamped value) and util/vectorized_pointwise.h:436-438 (forward: gate clamped to [-limit, limit] + offset),
+ * :543-553 (backward: the gate half's gradient is 0 where the clamp was active).
+ * mode 0: out [R, H]; mode 1: out [R, 2H]. */
+void te_clamped_swiglu_ref(int mode, const void *in, const void *grad, int dtype, float *out, size_t R, size_t H,
+                           float limit, float alpha, float offset) {
+  for (size_t r = 0; r < R; ++r)
+    for (size_t c = 0; c < H; ++c) {
+      const float a = load_in(in, r * 2 * H + c, dtype);
+      float g = load_in(in, r * 2 * H + H + c, dtype);
+      const float cv = fminf(a, limit);
+      const float s = sigmoid_ref(alpha * cv);
+      const float act = cv * s;
+      const int pass = g <= limit && g >= -limit;
+      g = fminf(fmaxf(-limit, g), limit) + offset;
+      if (mode == 0) {
+        out[r * H + c] = act * g;
+      } else {
+        const float dy = load_in(grad, r * H + c, dtype);
+        const float dact = a <= limit ? alpha * cv * (s * (1.f - s)) + s : 0.f;
+        out[r * 2 * H + c] = dact * dy * g;
+        out[r * 2 * H + H + c] = pass ? dy * act : 0.f;
+      }
+    }
+}
+
 int te_oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -13,7 +13,8 @@ import torch
 
 import oracle
 from helpers import FMT, randn_input, to_oracle_input, u8
-from transformer_engine_amd.activation import GATED, UNARY, activation, dactivation, dbias_dact
+from transformer_engine_amd.activation import (GATED, UNARY, activation, clamped_dswiglu, clamped_swiglu, dactivation,
+                                               dbias_dact)
 from transformer_engine_amd.tensor import DType, Float8CurrentScalingQuantizer, Float8Quantizer
 
 pytestmark = pytest.mark.gpu
@@ -216,3 +217,48 @@ def test_quantize_dbias_mxfp8_fused_pass_equals_plain_quantize():
         ref = oracle.colsum(to_oracle_input(dy))
         assert np.allclose(dbias.float().cpu().numpy(), ref, rtol=2 ** -7,
                            atol=2 ** -7 * np.abs(dy.float().cpu().numpy()).sum(axis=0).max())
+
+
+# ---------------------------------------------------------------- clamped SwiGLU (GPT-OSS), ref activation.h:346-370,487-512
+CLAMP = dict(limit=1.5, alpha=1.702)      # a limit inside the data range, so that every clamp branch is taken
+
+
+@pytest.mark.parametrize("offset", [1.0, 0.25])
+@pytest.mark.parametrize("N,H", [(256, 512), (304, 264), (37, 100)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_clamped_swiglu_forward_backward_high_precision(offset, N, H, dtype):
+    x = randn_input((N, 2 * H), dtype, 41) * 2
+    g = randn_input((N, H), dtype, 42)
+    y = clamped_swiglu(x, glu_linear_offset=offset, **CLAMP)
+    dx = clamped_dswiglu(g, x, glu_linear_offset=offset, **CLAMP)
+    torch.cuda.synchronize()
+    ref_y = oracle.clamped_swiglu(to_oracle_input(x), offset=offset, **CLAMP)
+    ref_dx = oracle.clamped_swiglu(to_oracle_input(x), to_oracle_input(g), offset=offset, **CLAMP)
+    # ref test_act.cu getTolerances: fp32 atol 1e-6 rtol 5e-6 (widened for device exp2/rcp: 1e-5 / 2e-5), bf16 1e-5 / 1e-2
+    rtol, atol = (1e-2, 1e-5) if dtype == torch.bfloat16 else (2e-5, 1e-5)
+    assert np.allclose(y.float().cpu().numpy(), ref_y, rtol=rtol, atol=atol * max(1.0, np.abs(ref_y).max()))
+    assert np.allclose(dx.float().cpu().numpy(), ref_dx, rtol=rtol, atol=atol * max(1.0, np.abs(ref_dx).max()))
+    # the clamp branches exist in this data: saturated activations, clamped gates with zero gate gradient
+    xf = x.float().cpu().numpy()
+    assert (xf[:, :H] > CLAMP["limit"]).any() and (np.abs(xf[:, H:]) > CLAMP["limit"]).any()
+    assert (ref_dx[:, H:][np.abs(xf[:, H:]) > CLAMP["limit"]] == 0).all()
+    assert (dx.float().cpu().numpy()[:, H:][np.abs(xf[:, H:]) > CLAMP["limit"]] == 0).all()
+
+
+@pytest.mark.parametrize("N,H", [(256, 512), (96, 160)])
+def test_clamped_swiglu_quantized_outputs_equal_unfused(N, H):
+    x = randn_input((N, 2 * H), torch.bfloat16, 43) * 2
+    g = randn_input((N, H), torch.bfloat16, 44)
+    # FP8 per-tensor (delayed) scaling: codes against the oracle as for the other gated activations
+    scale, amax = torch.full((1,), 3.0, device="cuda"), torch.zeros(1, device="cuda")
+    out = clamped_swiglu(x, Float8Quantizer(scale, amax, E4), **CLAMP)
+    torch.cuda.synchronize()
+    _check_fp8(out, oracle.clamped_swiglu(to_oracle_input(x), **CLAMP), 3.0, E4, amax.item())
+    amax.zero_()
+    out = clamped_dswiglu(g, x, Float8Quantizer(scale, amax, E5), **CLAMP)
+    torch.cuda.synchronize()
+    _check_fp8(out, oracle.clamped_swiglu(to_oracle_input(x), to_oracle_input(g), **CLAMP), 3.0, E5, amax.item())
+    # MXFP8: fused == activation, then nvte_quantize
+    q = _mx_quantizer("compact")
+    _assert_same_mxfp8(clamped_swiglu(x, q, **CLAMP), q(clamped_swiglu(x, **CLAMP)), N, H, "compact")
+    _assert_same_mxfp8(clamped_dswiglu(g, x, q, **CLAMP), q(clamped_dswiglu(g, x, **CLAMP)), N, 2 * H, "compact")

@@ -198,6 +198,10 @@ _SIGS = {
     "nvte_reglu": (_V, [_P, _P, _P]),
     "nvte_qgeglu": (_V, [_P, _P, _P]),
     "nvte_sreglu": (_V, [_P, _P, _P]),
+    "nvte_clamped_swiglu": (_V, [_P, _P, _F, _F, _P]),
+    "nvte_clamped_swiglu_v2": (_V, [_P, _P, _F, _F, _F, _P]),
+    "nvte_clamped_dswiglu": (_V, [_P, _P, _P, _F, _F, _P]),
+    "nvte_clamped_dswiglu_v2": (_V, [_P, _P, _P, _F, _F, _F, _P]),
     "nvte_dgelu": (_V, [_P, _P, _P, _P]),
     "nvte_dsilu": (_V, [_P, _P, _P, _P]),
     "nvte_drelu": (_V, [_P, _P, _P, _P]),

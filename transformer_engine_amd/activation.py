@@ -4,6 +4,7 @@
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -75,6 +76,38 @@ def dactivation(name: str, grad: torch.Tensor, x: torch.Tensor, quantizer=None):
     wg, wi = wrap_plain(g2), wrap_plain(x2)
     try:
         getattr(api, "nvte_d" + name)(wg.handle, wi.handle, wo.handle, current_stream_ptr())
+    finally:
+        wg.destroy(); wi.destroy(); wo.destroy()
+    return _finish(out, hp, quantizer)
+
+
+def clamped_swiglu(x: torch.Tensor, quantizer=None, *, limit: float = 7.0, alpha: float = 1.702,
+                   glu_linear_offset: float = 1.0):
+    """tex.clamped_swiglu (GPT-OSS): act(a) * (clamp(g) + offset), input [..., 2H] -> [..., H]."""
+    x2 = x.reshape(-1, x.shape[-1])
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    out, wo, hp = _make_out((x2.shape[0], x2.shape[1] // 2), x2, quantizer)
+    wi = wrap_plain(x2)
+    try:
+        api.nvte_clamped_swiglu_v2(wi.handle, wo.handle, C.c_float(limit), C.c_float(alpha),
+                                   C.c_float(glu_linear_offset), current_stream_ptr())
+    finally:
+        wi.destroy(); wo.destroy()
+    return _finish(out, hp, quantizer)
+
+
+def clamped_dswiglu(grad: torch.Tensor, x: torch.Tensor, quantizer=None, *, limit: float = 7.0,
+                    alpha: float = 1.702, glu_linear_offset: float = 1.0):
+    """tex.clamped_dswiglu: grad [..., H], forward input [..., 2H] -> [..., 2H]."""
+    x2 = x.reshape(-1, x.shape[-1])
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    g2 = grad.reshape(-1, grad.shape[-1])
+    g2 = g2 if g2.is_contiguous() else g2.contiguous()
+    out, wo, hp = _make_out(tuple(x2.shape), x2, quantizer)
+    wg, wi = wrap_plain(g2), wrap_plain(x2)
+    try:
+        api.nvte_clamped_dswiglu_v2(wg.handle, wi.handle, wo.handle, C.c_float(limit), C.c_float(alpha),
+                                    C.c_float(glu_linear_offset), current_stream_ptr())
     finally:
         wg.destroy(); wi.destroy(); wo.destroy()
     return _finish(out, hp, quantizer)

@@ -34,7 +34,7 @@ bool cast_transpose_dbias_tile_launch(const Tensor &in, Tensor &out, float *part
 
 namespace {
 
-enum : int { kActNone = 0, kActGelu, kActSilu, kActRelu, kActQGelu, kActSRelu, kActSigmoid };
+enum : int { kActNone = 0, kActGelu, kActSilu, kActRelu, kActQGelu, kActSRelu, kActSigmoid, kActClampedSilu };
 enum : int { kUnary = 0, kDAct = 1, kGatedFwd = 2, kGatedBwd = 3 };
 enum : int { kOutE4M3 = 0, kOutE5M2 = 1, kOutHP = 2, kOutMXE4M3 = 3, kOutMXE5M2 = 4 };
 
@@ -91,6 +91,19 @@ __device__ __forceinline__ float act_c(float x) { return act_f(ID, x); }
 template <int ID>
 __device__ __forceinline__ float dact_c(float x) { return dact_f(ID, x); }
 
+// clamped SwiGLU (GPT-OSS): act(x) = c * sigmoid(alpha c) with c = min(x, limit); its derivative is 0 above
+// the limit; the linear half is clamped to [-limit, limit] and shifted by glu_offset, and its gradient is 0
+// where the clamp was active (ref math.h:80-98, vectorized_pointwise.h:436-438,543-546)
+__device__ __forceinline__ float clamped_act(float x, float limit, float alpha) {
+  const float c = fminf(x, limit);
+  return c * sigmoid_f(alpha * c);
+}
+__device__ __forceinline__ float clamped_dact(float x, float limit, float alpha) {
+  const float c = fminf(x, limit);
+  const float s = sigmoid_f(alpha * c);
+  return x <= limit ? alpha * c * s * (1.f - s) + s : 0.f;
+}
+
 struct FusedArgs {
   const void *in;    // unary: input; d-act / gated: the activation input ([R, H] or [R, 2H])
   const void *grad;  // d-act / gated backward: incoming gradient [R, H]
@@ -107,6 +120,8 @@ struct FusedArgs {
   uint8_t *mx_col, *sc_row, *sc_col;
   unsigned stride_r, stride_c;  // second dims of the two scale arrays
   int swz, tcol;                // GEMM-swizzled scales; column-wise payload stored transposed (amd_ext.h)
+  // clamped SwiGLU (ref math.h:80-98, vectorized_pointwise.h:436-438,543-546)
+  float limit, alpha, glu_offset;
 };
 
 // compact -> GEMM-swizzled scale index (ref common/cast/mxfp8/swizzle.cuh:30-41; twin of mxfp8.hip)
@@ -114,6 +129,42 @@ __device__ __forceinline__ size_t mx_swizzled_idx(size_t i, size_t j, size_t til
   const size_t tile = (i / 128) * tiles_x + (j / 4);
   const size_t y = i % 128, x = j % 4;
   return tile * 512 + (y % 32) * 16 + (y / 32) * 4 + x;
+}
+
+// activation / derivative / linear-half transform with the launch's parameters (compile-time id)
+template <int ACT>
+__device__ __forceinline__ float act_p(float x, const FusedArgs &a) {
+  if constexpr (ACT == kActClampedSilu) return clamped_act(x, a.limit, a.alpha);
+  else return act_c<ACT>(x);
+}
+template <int ACT>
+__device__ __forceinline__ float dact_p(float x, const FusedArgs &a) {
+  if constexpr (ACT == kActClampedSilu) return clamped_dact(x, a.limit, a.alpha);
+  else return dact_c<ACT>(x);
+}
+// returns the value the linear half contributes; `pass` = its gradient flows (clamp inactive)
+template <int ACT>
+__device__ __forceinline__ float gate_p(float g, const FusedArgs &a, bool &pass) {
+  if constexpr (ACT == kActClampedSilu) {
+    pass = g <= a.limit && g >= -a.limit;
+    return fminf(fmaxf(-a.limit, g), a.limit) + a.glu_offset;
+  } else {
+    pass = true;
+    return g;
+  }
+}
+// the same with a run-time id (element-wise kernels)
+__device__ __forceinline__ float act_r(float x, const FusedArgs &a) {
+  return a.act == kActClampedSilu ? clamped_act(x, a.limit, a.alpha) : act_f(a.act, x);
+}
+__device__ __forceinline__ float dact_r(float x, const FusedArgs &a) {
+  return a.act == kActClampedSilu ? clamped_dact(x, a.limit, a.alpha) : dact_f(a.act, x);
+}
+__device__ __forceinline__ float gate_r(float g, const FusedArgs &a, bool &pass) {
+  pass = true;
+  if (a.act != kActClampedSilu) return g;
+  pass = g <= a.limit && g >= -a.limit;
+  return fminf(fmaxf(-a.limit, g), a.limit) + a.glu_offset;
 }
 
 constexpr int kTile = 128;
@@ -309,13 +360,17 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           float v;
-          if constexpr (MODE == kUnary) v = act_c<ACT>(x0[k]);
-          if constexpr (MODE == kDAct) v = g[k] * dact_c<ACT>(x0[k]);
-          if constexpr (MODE == kGatedFwd) v = act_c<ACT>(x0[k]) * x1[k];
-          if constexpr (MODE == kGatedBwd) {
-            const float va = dact_c<ACT>(x0[k]) * g[k] * x1[k];
-            const float vg = g[k] * act_c<ACT>(x0[k]);
-            v = o == 0 ? va : vg;
+          if constexpr (MODE == kUnary) v = act_p<ACT>(x0[k], a);
+          if constexpr (MODE == kDAct) v = g[k] * dact_p<ACT>(x0[k], a);
+          if constexpr (GATED) {
+            bool pass;
+            const float lin = gate_p<ACT>(x1[k], a, pass);
+            if constexpr (MODE == kGatedFwd) v = act_p<ACT>(x0[k], a) * lin;
+            if constexpr (MODE == kGatedBwd) {
+              const float va = dact_p<ACT>(x0[k], a) * g[k] * lin;
+              const float vg = pass ? g[k] * act_p<ACT>(x0[k], a) : 0.f;
+              v = o == 0 ? va : vg;
+            }
           }
           if constexpr (DBIAS) cs[k] += v;  // NOUT == 1 whenever DBIAS
           // the block quantize sees the value rounded to the input dtype, i.e. what the unfused
@@ -340,12 +395,16 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
     float v[NOUT][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if constexpr (MODE == kUnary) v[0][k] = act_c<ACT>(x0[k]);
-      if constexpr (MODE == kDAct) v[0][k] = g[k] * dact_c<ACT>(x0[k]);
-      if constexpr (MODE == kGatedFwd) v[0][k] = act_c<ACT>(x0[k]) * x1[k];
-      if constexpr (MODE == kGatedBwd) {
-        v[0][k] = dact_c<ACT>(x0[k]) * g[k] * x1[k];
-        v[1][k] = g[k] * act_c<ACT>(x0[k]);
+      if constexpr (MODE == kUnary) v[0][k] = act_p<ACT>(x0[k], a);
+      if constexpr (MODE == kDAct) v[0][k] = g[k] * dact_p<ACT>(x0[k], a);
+      if constexpr (GATED) {
+        bool pass;
+        const float lin = gate_p<ACT>(x1[k], a, pass);
+        if constexpr (MODE == kGatedFwd) v[0][k] = act_p<ACT>(x0[k], a) * lin;
+        if constexpr (MODE == kGatedBwd) {
+          v[0][k] = dact_p<ACT>(x0[k], a) * g[k] * lin;
+          v[1][k] = pass ? g[k] * act_p<ACT>(x0[k], a) : 0.f;
+        }
       }
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
@@ -418,11 +477,13 @@ __global__ __launch_bounds__(256) void fused_act_general_kernel(const FusedArgs 
     const float x1 = (mode == kGatedFwd || mode == kGatedBwd) ? load1(a.in, r * a.ld_in + a.cols + c, a.in_dtype) : 0.f;
     const float g = (mode == kDAct || mode == kGatedBwd) ? load1(a.grad, i, a.in_dtype) : 0.f;
     float v[2] = {0.f, 0.f};
+    bool pass;
+    const float lin = gate_r(x1, a, pass);
     switch (mode) {
-      case kUnary: v[0] = act_f(a.act, x0); break;
-      case kDAct: v[0] = g * dact_f(a.act, x0); break;
-      case kGatedFwd: v[0] = act_f(a.act, x0) * x1; break;
-      default: v[0] = dact_f(a.act, x0) * g * x1; v[1] = g * act_f(a.act, x0); break;
+      case kUnary: v[0] = act_r(x0, a); break;
+      case kDAct: v[0] = g * dact_r(x0, a); break;
+      case kGatedFwd: v[0] = act_r(x0, a) * lin; break;
+      default: v[0] = dact_r(x0, a) * g * lin; v[1] = pass ? g * act_r(x0, a) : 0.f; break;
     }
     if (a.dbias_part) atomicAdd(a.dbias_part + c, v[0]);
     for (int o = 0; o < nout; ++o) {
@@ -462,11 +523,13 @@ __global__ __launch_bounds__(256) void fused_act_mx_general_kernel(const FusedAr
       const float x0 = load1(a.in, r * a.ld_in + c, a.in_dtype);
       const float x1 = (mode == kGatedFwd || mode == kGatedBwd) ? load1(a.in, r * a.ld_in + a.cols + c, a.in_dtype) : 0.f;
       const float g = (mode == kDAct || mode == kGatedBwd) ? load1(a.grad, r * a.cols + c, a.in_dtype) : 0.f;
+      bool pass;
+      const float lin = gate_r(x1, a, pass);
       switch (mode) {
-        case kUnary: v = act_f(a.act, x0); break;
-        case kDAct: v = g * dact_f(a.act, x0); break;
-        case kGatedFwd: v = act_f(a.act, x0) * x1; break;
-        default: v = o == 0 ? dact_f(a.act, x0) * g * x1 : g * act_f(a.act, x0); break;
+        case kUnary: v = act_r(x0, a); break;
+        case kDAct: v = g * dact_r(x0, a); break;
+        case kGatedFwd: v = act_r(x0, a) * lin; break;
+        default: v = o == 0 ? dact_r(x0, a) * g * lin : (pass ? g * act_r(x0, a) : 0.f); break;
       }
       if (a.dbias_part) atomicAdd(a.dbias_part + c, v);
       v = round_to(v, a.in_dtype);
@@ -529,7 +592,8 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 template <typename IT, int OK, int MODE, int ACT>
 void launch_tile(const FusedArgs &a, bool dbias, unsigned grid, hipStream_t stream) {
   // combinations that exist: the identity only as a plain cast, the sigmoid only as the GLU gate
-  constexpr bool valid = (ACT != kActNone || MODE == kUnary) && (ACT != kActSigmoid || MODE == kGatedFwd || MODE == kGatedBwd);
+  constexpr bool valid = (ACT != kActNone || MODE == kUnary) &&
+                         ((ACT != kActSigmoid && ACT != kActClampedSilu) || MODE == kGatedFwd || MODE == kGatedBwd);
   if constexpr (!valid) {
     NVTE_ERROR("invalid activation / mode combination");
   } else {
@@ -553,6 +617,7 @@ void launch_tile_by_act(const FusedArgs &a, bool dbias, unsigned grid, hipStream
     case kActQGelu: launch_tile<IT, OK, MODE, kActQGelu>(a, dbias, grid, stream); break;
     case kActSRelu: launch_tile<IT, OK, MODE, kActSRelu>(a, dbias, grid, stream); break;
     case kActSigmoid: launch_tile<IT, OK, MODE, kActSigmoid>(a, dbias, grid, stream); break;
+    case kActClampedSilu: launch_tile<IT, OK, MODE, kActClampedSilu>(a, dbias, grid, stream); break;
     default: launch_tile<IT, OK, MODE, kActNone>(a, dbias, grid, stream); break;
   }
 }
@@ -580,8 +645,12 @@ void launch_tile_by_input(int mode, const FusedArgs &a, bool dbias, unsigned gri
 
 // mode / act: the enums above.  grad may be null (unary, gated forward); dbias + workspace are both
 // null or both given (two-call protocol: an empty workspace only reports its shape).
+struct ClampParams {
+  float limit = 0.f, alpha = 0.f, glu_offset = 0.f;
+};
+
 void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, Tensor &out, Tensor *dbias,
-                      Tensor *workspace, hipStream_t stream) {
+                      Tensor *workspace, hipStream_t stream, const ClampParams &cp = ClampParams()) {
   const bool gated = mode == kGatedFwd || mode == kGatedBwd;
   const size_t rows = in.rows();
   NVTE_CHECK(!gated || in.cols() % 2 == 0, "Gated activation input must have an even last dimension, got ", in.cols());
@@ -630,6 +699,9 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
     a.in_dtype = in.data.dtype;
     a.out_dtype = odt;
     a.act = act;
+    a.limit = cp.limit;
+    a.alpha = cp.alpha;
+    a.glu_offset = cp.glu_offset;
     a.swz = out.with_gemm_swizzled_scales ? 1 : 0;
     a.tcol = out.columnwise_transposed ? 1 : 0;
     if (out.has_data()) {
@@ -716,6 +788,9 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
   a.in_dtype = in.data.dtype;
   a.out_dtype = odt;
   a.act = act;
+  a.limit = cp.limit;
+  a.alpha = cp.alpha;
+  a.glu_offset = cp.glu_offset;
 
   const size_t slabs = ceil_div(rows, kSlab);
   // plain cast + transpose + dbias on whole tiles: the tuned cast_transpose tile kernel itself
@@ -824,6 +899,30 @@ TE_DBIAS_DACT(nvte_cast_transpose_dbias_dsilu, kActSilu)
 TE_DBIAS_DACT(nvte_cast_transpose_dbias_drelu, kActRelu)
 TE_DBIAS_DACT(nvte_cast_transpose_dbias_dqgelu, kActQGelu)
 TE_DBIAS_DACT(nvte_cast_transpose_dbias_dsrelu, kActSRelu)
+
+// ref activation.h:346-370,487-512: the GPT-OSS gated Swish (clamped pre-activation and gate, sigmoid(alpha x));
+// the un-suffixed forms are the deprecated ones with glu_linear_offset = 1
+void nvte_clamped_swiglu_v2(const NVTETensor input, NVTETensor output, float limit, float alpha,
+                            float glu_linear_offset, hipStream_t stream) {
+  api_guard("nvte_clamped_swiglu_v2", [&] {
+    fused_act_launch(kGatedFwd, kActClampedSilu, nullptr, *lookup_checked(input), *lookup_checked(output), nullptr,
+                     nullptr, stream, ClampParams{limit, alpha, glu_linear_offset});
+  });
+}
+void nvte_clamped_swiglu(const NVTETensor input, NVTETensor output, float limit, float alpha, hipStream_t stream) {
+  nvte_clamped_swiglu_v2(input, output, limit, alpha, 1.0f, stream);
+}
+void nvte_clamped_dswiglu_v2(const NVTETensor grad, const NVTETensor input, NVTETensor output, float limit,
+                             float alpha, float glu_linear_offset, hipStream_t stream) {
+  api_guard("nvte_clamped_dswiglu_v2", [&] {
+    fused_act_launch(kGatedBwd, kActClampedSilu, lookup_checked(grad), *lookup_checked(input),
+                     *lookup_checked(output), nullptr, nullptr, stream, ClampParams{limit, alpha, glu_linear_offset});
+  });
+}
+void nvte_clamped_dswiglu(const NVTETensor grad, const NVTETensor input, NVTETensor output, float limit,
+                          float alpha, hipStream_t stream) {
+  nvte_clamped_dswiglu_v2(grad, input, output, limit, alpha, 1.0f, stream);
+}
 
 // ref transpose.h:242-318: (input = grad, act_input, output)
 #define TE_DGATED_CT(name, act_id)                                                                      \
