@@ -26,6 +26,7 @@ def run(m_splits, tag):
     ts = sorted(timeit(f) for _ in range(5))
     print(f"{tag}: {ts[2]*1e3:.1f} us  {2*M*N*K/ts[2]/1e9:.0f} TF")
 run([8192], "G=1 m=8192")
+run([16384], "G=1 m=16384 (one weight, the plain-GEMM equivalent of the C5 size)")
 run([2048] * 8, "G=8 m=2048 each")
 run([2080, 1936, 2048, 2048, 2160, 2112, 2032, 2032], "G=8 ragged")
 run([2048] * 4, "G=4 m=2048 each")
