@@ -97,3 +97,51 @@ def test_gemm_and_reduce_scatter_overlap_schedule():
 
 def test_amax_max_reduction():
     _run("_case_amax_reduction")
+
+
+# ---------------------------------------------------------------- FP8 weight update: the exchange step
+def _case_weight_update_amax_exchange(rank, world):
+    """quantize_master_weights' only collective: ONE MAX all-reduce of the packed amaxes; ranks that
+    hold no shard of a weight contribute 0 (ref pytorch/tensor/utils.py:322-365)."""
+    from transformer_engine_amd import weight_update as WU
+    packed = torch.zeros(5)
+    mine = {0: [0.5, 0.0, 3.0, 0.0, 1.0], 1: [0.25, 7.0, 2.0, 0.0, 1.5]}[rank]
+    packed.copy_(torch.tensor(mine))
+    WU._all_reduce_max(packed, None)
+    assert torch.equal(packed, torch.tensor([0.5, 7.0, 3.0, 0.0, 1.5]))
+    # bf16 block amaxes travel in the master dtype (MXFP8 path, ref :841-883)
+    blk = torch.tensor([rank + 1.0, 0.0, 4.0 - rank], dtype=torch.bfloat16)
+    WU._all_reduce_max(blk, None)
+    assert torch.equal(blk, torch.tensor([2.0, 0.0, 4.0], dtype=torch.bfloat16))
+
+
+def test_weight_update_amax_exchange():
+    _run("_case_weight_update_amax_exchange")
+
+
+def test_weight_update_host_checks():
+    """Host logic of the shard bookkeeping (no GPU): offsets are validated before any kernel, CPU
+    tensors are refused (there is no CPU fallback), list lengths must agree."""
+    from transformer_engine_amd import weight_update as WU
+
+    class W:  # stand-in for a model weight: only numel() is consulted
+        def numel(self):
+            return 100
+
+    m = torch.zeros(40)
+    assert WU._check_shard(W(), m, 60) == 100
+    with pytest.raises(ValueError, match="must not be None"):
+        WU._check_shard(W(), m, None)
+    with pytest.raises(ValueError, match="non-negative"):
+        WU._check_shard(W(), m, -1)
+    with pytest.raises(ValueError, match="exceeds model_weight numel"):
+        WU._check_shard(W(), m, 61)
+    with pytest.raises(ValueError, match="same length"):
+        WU._Lists([[m], [m, m]])
+    with pytest.raises(RuntimeError, match="GPU only"):
+        WU._Lists([[m], [m]])
+    with pytest.raises(ValueError, match="not supported yet"):
+        class MW:
+            _quantizer = object()
+            dtype = torch.float32
+        WU.quantize_master_weights([MW()], [None], [None], None)
