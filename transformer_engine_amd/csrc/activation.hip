@@ -732,6 +732,10 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
                                "swizzled column-wise scales need (128, 4) padding");
     }
     if (rows == 0 || H == 0) return;
+    NVTE_REQUIRE_DATA(in.data, "activation input");
+    if (grad) NVTE_REQUIRE_DATA(grad->data, "grad");
+    if (out.has_data()) NVTE_REQUIRE_DATA(out.data, "output");
+    if (out.has_columnwise_data()) NVTE_REQUIRE_DATA(out.columnwise_data, "column-wise output");
     (void)device_info();
     if (a.amax) NVTE_CHECK_HIP(hipMemsetAsync(a.amax, 0, sizeof(float), stream));
     const size_t slabs = ceil_div(rows, kSlab);
@@ -769,6 +773,10 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
   }
   NVTE_CHECK(rows < (1ull << 31) && out_cols < (1ull << 31), "tensor too large");
   if (rows == 0 || H == 0) return;
+  NVTE_REQUIRE_DATA(in.data, "activation input");
+  if (grad) NVTE_REQUIRE_DATA(grad->data, "grad");
+  if (out.has_data()) NVTE_REQUIRE_DATA(out.data, "output");
+  if (out.has_columnwise_data()) NVTE_REQUIRE_DATA(out.columnwise_data, "column-wise output");
   (void)device_info();
 
   FusedArgs a;

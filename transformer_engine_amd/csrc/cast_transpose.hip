@@ -369,6 +369,9 @@ void cast_transpose_launch(const Tensor &in, const float *noop, Tensor &out, hip
   NVTE_CHECK(out.scale_inv.ptr == out.columnwise_scale_inv.ptr,
              "Cast and transposed outputs need to share scale-inverse tensor.");
   if (rows == 0 || cols == 0) return;
+  NVTE_REQUIRE_DATA(in.data, "cast_transpose input");
+  NVTE_REQUIRE_DATA(out.data, "cast_transpose output");
+  NVTE_REQUIRE_DATA(out.columnwise_data, "cast_transpose transposed output");
 
   const bool fp8_out = is_fp8(out.data.dtype);
   const bool fast = fp8_out && rows % kTile == 0 && cols % kTile == 0 && aligned16(in.data.ptr) &&
@@ -425,6 +428,8 @@ void cast_rowwise_launch(const Tensor &in, const float *noop, Tensor &out, hipSt
              scaling_mode_name(out.scaling_mode));
   const size_t n = in.data.numel();
   if (n == 0) return;
+  NVTE_REQUIRE_DATA(in.data, "cast input");
+  NVTE_REQUIRE_DATA(out.data, "cast output");
   const bool fp8_out = is_fp8(out.data.dtype);
   const bool fast = fp8_out && n % 16 == 0 && aligned16(in.data.ptr) && aligned16(out.data.ptr);
   TE_SWITCH_IN(in.data.dtype, IT, {

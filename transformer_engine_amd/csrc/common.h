@@ -127,6 +127,12 @@ struct Buf {
   void reset() { *this = Buf(); }
 };
 
+// A descriptor may carry a shape without a pointer (workspace queries, shape-only scale swizzles); a
+// launcher that is about to hand the pointer to a kernel calls this first: a null pointer with a
+// non-empty shape must end as an error here, not as a memory fault on the GPU.
+#define NVTE_REQUIRE_DATA(buf, what) \
+  NVTE_CHECK((buf).ptr != nullptr || (buf).numel() == 0, what, " has a shape but no data pointer")
+
 inline bool same_shape(const NVTEShape &a, const NVTEShape &b) {
   if (a.ndim != b.ndim) return false;
   for (size_t i = 0; i < a.ndim; ++i)

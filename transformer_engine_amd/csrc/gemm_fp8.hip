@@ -953,6 +953,8 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   g.P = opB.data;
   g.Q = opA.data;
   g.D = D.data.ptr;
+  NVTE_CHECK(g.P != nullptr && g.Q != nullptr, "GEMM operands have shapes but no data pointers");
+  NVTE_CHECK(g.D != nullptr, "GEMM output D has a shape but no data pointer");
   g.bias_dtype = has_bias ? bias->data.dtype : kNVTEFloat32;
   if (mx) {
     g.eP = static_cast<const uint8_t *>(opB.scale_inv);

@@ -469,6 +469,9 @@ void mxfp8_quantize_launch(const Tensor &in, const float *noop, Tensor &out, hip
     }
   }
   if (in.data.numel() == 0) return;
+  NVTE_REQUIRE_DATA(in.data, "MXFP8 quantize input");
+  if (row) NVTE_REQUIRE_DATA(out.data, "MXFP8 row-wise output");
+  if (col) NVTE_REQUIRE_DATA(out.columnwise_data, "MXFP8 column-wise output");
   const bool e4 = out.dtype() == kNVTEFloat8E4M3;
   switch (in.data.dtype) {
     case kNVTEBFloat16:

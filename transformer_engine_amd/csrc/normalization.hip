@@ -512,6 +512,8 @@ void norm_fwd(bool is_ln, const Tensor &x, const Tensor &gamma, const Tensor *be
 
   NormFwdArgs a;
   std::memset(&a, 0, sizeof(a));
+  NVTE_REQUIRE_DATA(x.data, "x");
+  NVTE_REQUIRE_DATA(gamma.data, "gamma");
   a.x = x.data.ptr;
   a.gamma = gamma.data.ptr;
   a.beta = is_ln ? beta->data.ptr : nullptr;
@@ -597,6 +599,8 @@ void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, c
   NormBwdArgs a;
   std::memset(&a, 0, sizeof(a));
   a.dz = dz.data.ptr;
+  NVTE_REQUIRE_DATA(x.data, "x");
+  NVTE_REQUIRE_DATA(gamma.data, "gamma");
   a.x = x.data.ptr;
   a.gamma = gamma.data.ptr;
   a.add = add ? add->data.ptr : nullptr;

@@ -206,6 +206,8 @@ void dequantize_launch(const Tensor &in, Tensor &out, hipStream_t stream) {
   NVTE_CHECK(same_shape(out.data.shape, in.data.shape), "Input and output shapes need to match.");
   const size_t n = in.data.numel();
   if (n == 0) return;
+  NVTE_REQUIRE_DATA(in.data, "dequantize input");
+  NVTE_REQUIRE_DATA(out.data, "dequantize output");
   NVTE_CHECK(in.scale_inv.ptr != nullptr, "Input scale_inv is not allocated.");
   if (in.data.dtype == kNVTEFloat8E4M3)
     dequant_by_out<Fp8::E4M3>(in, out, n, stream);
