@@ -516,6 +516,11 @@ void norm_fwd(bool is_ln, const Tensor &x, const Tensor &gamma, const Tensor *be
   NVTE_REQUIRE_DATA(gamma.data, "gamma");
   a.x = x.data.ptr;
   a.gamma = gamma.data.ptr;
+  if (is_ln) {
+    NVTE_REQUIRE_DATA(beta->data, "beta");
+    NVTE_CHECK(mu->data.ptr != nullptr, "mu is not allocated");
+  }
+  NVTE_CHECK(rsigma->data.ptr != nullptr, "rsigma is not allocated");
   a.beta = is_ln ? beta->data.ptr : nullptr;
   a.mu = is_ln ? static_cast<float *>(mu->data.ptr) : nullptr;
   a.rs = static_cast<float *>(rsigma->data.ptr);
@@ -530,6 +535,7 @@ void norm_fwd(bool is_ln, const Tensor &x, const Tensor &gamma, const Tensor *be
     a.z_dtype = x.data.dtype;
   } else {
     NVTE_CHECK(z->has_data(), "Output z needs row-wise data");
+    NVTE_REQUIRE_DATA(z->data, "z");
     a.z = z->data.ptr;
     a.z_dtype = z->data.dtype;
     if (is_fp8(z->data.dtype)) {
@@ -598,6 +604,15 @@ void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, c
   (void)device_info();
   NormBwdArgs a;
   std::memset(&a, 0, sizeof(a));
+  NVTE_REQUIRE_DATA(dz.data, "dz");
+  NVTE_REQUIRE_DATA(dx->data, "dx");
+  NVTE_REQUIRE_DATA(dgamma->data, "dgamma");
+  if (is_ln) {
+    NVTE_REQUIRE_DATA(dbeta->data, "dbeta");
+    NVTE_CHECK(mu->data.ptr != nullptr, "mu is not allocated");
+  }
+  if (add) NVTE_REQUIRE_DATA(add->data, "add");
+  NVTE_CHECK(rsigma.data.ptr != nullptr && workspace->data.ptr != nullptr, "rsigma / workspace are not allocated");
   a.dz = dz.data.ptr;
   NVTE_REQUIRE_DATA(x.data, "x");
   NVTE_REQUIRE_DATA(gamma.data, "gamma");
