@@ -415,6 +415,8 @@ void nvte_group_compute_amax_with_config(const NVTEGroupedTensor input_, NVTEGro
     if (!out.all_same_last_dim()) NVTE_CHECK(g.last_dims, "Grouped amax requires last_dims for varying last dimensions.");
     const float *noop = noop_of(config);
     float *amax = static_cast<float *>(out.amax.ptr ? out.amax.ptr : out.columnwise_amax.ptr);
+    NVTE_CHECK(amax != nullptr, "Grouped amax buffer has no data pointer");
+    NVTE_REQUIRE_DATA(in.data, "grouped amax input");
     (void)device_info();
     const unsigned T = static_cast<unsigned>(out.num_tensors);
     hipLaunchKernelGGL(group_zero_amax_kernel, dim3(ceil_div(T, 256)), dim3(256), 0, stream, amax, T, noop);
@@ -517,6 +519,9 @@ void nvte_group_quantize(const NVTEGroupedTensor input_, NVTEGroupedTensor outpu
     uint8_t *oc = static_cast<uint8_t *>(out.data.ptr);
     uint8_t *ot = static_cast<uint8_t *>(out.columnwise_data.ptr);
     const float *sc = static_cast<const float *>(out.scale.ptr);
+    NVTE_REQUIRE_DATA(in.data, "grouped quantize input");
+    NVTE_CHECK(oc != nullptr || ot != nullptr, "grouped quantize output has shapes but no data pointers");
+    NVTE_CHECK(sc != nullptr, "grouped quantize output scale has no data pointer");
     const int al = aligned16(in.data.ptr) && (!oc || aligned16(oc)) && (!ot || aligned16(ot));
     const dim3 grid(static_cast<unsigned>(tiles)), block(256);
 #define TE_GQ_LAUNCH(IT_, F_)                                                                         \
@@ -552,6 +557,8 @@ void nvte_group_dequantize(const NVTEGroupedTensor input_, NVTEGroupedTensor out
     const dim3 grid(static_cast<unsigned>(ceil_div(total, 1024))), block(256);
     const uint8_t *ip = static_cast<const uint8_t *>(in.data.ptr);
     const float *si = static_cast<const float *>(in.scale_inv.ptr);
+    NVTE_CHECK(ip != nullptr && si != nullptr && out.data.ptr != nullptr,
+               "grouped dequantize: input data, scale_inv and output need data pointers");
 #define TE_GD(F_, OT_) hipLaunchKernelGGL((group_dequant_kernel<F_, OT_>), grid, block, 0, stream, ip, \
                                           static_cast<OT_ *>(out.data.ptr), si, g)
 #define TE_GD_BY_OUT(F_)                                         \
