@@ -58,6 +58,7 @@ void dbias_launch(const Tensor &in, Tensor &dbias, Tensor &workspace, hipStream_
   NVTE_CHECK(dbias.data.dtype == in.data.dtype, "DBias must have the same type as input.");
   NVTE_CHECK(dbias.data.shape.ndim == 1 && dbias.data.shape.data[0] == cols, "Wrong shape of DBias.");
   NVTE_CHECK(dbias.data.ptr != nullptr, "DBias is not allocated.");
+  NVTE_REQUIRE_DATA(in.data, "dbias input");
   const size_t slabs = ceil_div(rows, kSlab);
   NVTE_CHECK(workspace.data.dtype == kNVTEFloat32 && workspace.data.numel() >= slabs * cols,
              "Workspace is too small (need ", slabs * cols, " fp32 entries)");
