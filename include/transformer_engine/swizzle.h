@@ -20,6 +20,9 @@ void nvte_multi_tensor_swizzle_scaling_factors(const NVTETensor *inputs, NVTETen
                                                const size_t num_tensors, hipStream_t stream);
 /* ref swizzle.h:70 */
 void nvte_unswizzle_scaling_factors(const NVTETensor input, NVTETensor output, hipStream_t stream);
+/* ref swizzle.h:84 */
+void nvte_multi_tensor_unswizzle_scaling_factors(const NVTETensor *inputs, NVTETensor *outputs,
+                                                 const size_t num_tensors, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,12 @@ void nvte_transpose(const NVTETensor input, NVTETensor transposed_output, hipStr
 /* ref transpose.h:60 */
 void nvte_cast_transpose_dbias(const NVTETensor input, NVTETensor output, NVTETensor dbias,
                                NVTETensor workspace, hipStream_t stream);
+/* ref transpose.h:79 (def. transpose/transpose_fusion.cu:498).  input FP8 [N, H] -> transposed_output
+ * FP8 [H, N] (same bytes) + dbias[H] = sum over N of float(input) * scale_inv, where scale_inv is the
+ * OUTPUT tensor's (as the reference reads it, transpose_fusion.cu:469), else the input's, else 1.
+ * Two-call workspace protocol: an empty workspace only gets its shape [ceil(N/128), H] fp32. */
+void nvte_fp8_transpose_dbias(const NVTETensor input, NVTETensor transposed_output, NVTETensor dbias,
+                              NVTETensor workspace, hipStream_t stream);
 /* ref transpose.h:93 */
 void nvte_multi_cast_transpose(size_t num_tensors, const NVTETensor *input_list,
                                NVTETensor *output_list, hipStream_t stream);

@@ -252,6 +252,30 @@ def test_grouped_gemm_fprop_exact(m_splits, discrete_a):
         r0 += m
 
 
+@pytest.mark.parametrize("sm_count", [1, 10, 100, 250])
+def test_grouped_gemm_capped_workgroup_count_exact(sm_count):
+    """kNVTEGroupedMatmulConfigSMCount caps the persistent grid.  With a grid that is not a multiple of 8
+    the XCD-aware remap sends a workgroup's NEXT tile to an earlier member (e.g. 100 tiles on 10
+    workgroups: workgroup 6 walks remapped tiles 76, 2, ...), so the member lookup must not assume that
+    tiles only move forward (gemm_fp8.hip member lookup)."""
+    m_splits = [512, 256, 0, 1280, 300, 768, 48, 1024]      # 4 tile columns x 17 tile rows + partial tiles
+    N, K = 1024, 256
+    G = len(m_splits)
+    sx = [0.5 ** (i % 4) for i in range(G)]
+    sw = [1.0 + i for i in range(G)]
+    X, xs = _int_group([(m, K) for m in m_splits], E4, 41, sx)
+    W, ws = _int_group([(N, K)] * G, E4, 42, sw)
+    out = _hp_group([(m, N) for m in m_splits], torch.float32, fill=torch.full((sum(m_splits) * N,), float("nan"), device="cuda"))
+    general_grouped_gemm_for_grouped_tensor(W, X, out, layout="TN", sm_count=sm_count)
+    torch.cuda.synchronize()
+    y = out.rowwise_data.cpu().numpy()
+    r0 = 0
+    for i, m in enumerate(m_splits):
+        ref = (xs[i] @ ws[i].T * np.float32(sx[i] * sw[i])).astype(np.float32)
+        assert np.array_equal(y[r0 * N:(r0 + m) * N].reshape(m, N), ref), f"member {i}"     # exact
+        r0 += m
+
+
 def test_grouped_gemm_dgrad_wgrad_exact_with_accumulate_and_alpha_beta():
     m_splits, N, K = [256, 48, 0, 512], 256, 384
     G = len(m_splits)

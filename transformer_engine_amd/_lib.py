@@ -128,6 +128,7 @@ _SIGS = {
     "nvte_cast_transpose": (_V, [_P, _P, _P]),
     "nvte_transpose": (_V, [_P, _P, _P]),
     "nvte_cast_transpose_dbias": (_V, [_P, _P, _P, _P, _P]),
+    "nvte_fp8_transpose_dbias": (_V, [_P, _P, _P, _P, _P]),
     "nvte_multi_cast_transpose": (_V, [_SZ, C.POINTER(_P), C.POINTER(_P), _P]),
     "nvte_transpose_with_noop": (_V, [_P, _P, _P, _P]),
     "nvte_cast_transpose_with_noop": (_V, [_P, _P, _P, _P]),
@@ -242,6 +243,7 @@ _SIGS = {
     "nvte_swizzle_scaling_factors": (_V, [_P, _P, _P]),
     "nvte_multi_tensor_swizzle_scaling_factors": (_V, [C.POINTER(_P), C.POINTER(_P), _SZ, _P]),
     "nvte_unswizzle_scaling_factors": (_V, [_P, _P, _P]),
+    "nvte_multi_tensor_unswizzle_scaling_factors": (_V, [C.POINTER(_P), C.POINTER(_P), _SZ, _P]),
     # multi_stream.h
     "nvte_get_num_compute_streams": (_I, []),
     "nvte_get_compute_stream": (_P, [_I]),

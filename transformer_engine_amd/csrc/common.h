@@ -322,6 +322,8 @@ void mxfp8_quantize_dbias_launch(const Tensor &in, Tensor &out, Tensor &dbias, T
                                  hipStream_t stream);
 void dequantize_launch(const Tensor &in, Tensor &out, hipStream_t stream);
 void transpose_launch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream);
+void fp8_transpose_dbias_launch(const Tensor &in, Tensor &out, Tensor &dbias, Tensor &workspace,
+                                hipStream_t stream);  // dbias.hip
 void amax_launch(const Tensor &in, float *amax, const float *noop, hipStream_t stream);
 void scale_from_amax_launch(const float *amax, float *scale, float max_fp8, bool pow2, float eps,
                             const float *noop, hipStream_t stream);

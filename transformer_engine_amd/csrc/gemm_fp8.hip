@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   const unsigned tiles_i = (a.n + BM - 1) / BM;
   const unsigned nk = (a.k + BK - 1) / BK;
   unsigned total_tiles = a.ntiles;
-  unsigned grp = 0;  // GROUPED: member that holds the tile located last (tiles only move forward)
+  unsigned grp = 0;  // GROUPED: member that holds the tile located last
   if constexpr (GROUPED) {
     total_tiles = a.group_tile_start[a.num_groups];
     if (blockIdx.x >= total_tiles) return;  // whole workgroup, before any barrier
@@ -232,12 +232,22 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       if (!valid) tile = 0;
       {
         // same XCD-aware remap as tile_of: the workgroups of one XCD (id % 8) walk a contiguous run
-        // of the global tile list, so an XCD's L2 holds few P / Q panels at a time.  A workgroup's
-        // successive tiles keep their XCD, hence still move forward through the members.
+        // of the global tile list, so an XCD's L2 holds few P / Q panels at a time.
         const unsigned q8 = total_tiles / 8, r8 = total_tiles % 8, xcd = tile % 8, loc = tile / 8;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
       }
-      while (grp + 1 < a.num_groups && tile >= a.group_tile_start[grp + 1]) ++grp;
+      // stateless member lookup (the member g with tile_start[g] <= tile < tile_start[g + 1]; empty
+      // members have equal bounds and are skipped): with a grid that is not a multiple of 8 (a
+      // caller-capped workgroup count) the remapped index of a workgroup's next tile can move
+      // backwards, so a running index would be wrong.
+      {
+        unsigned lo = 0, hi = a.num_groups - 1;
+        while (lo < hi) {
+          const unsigned mid = (lo + hi) >> 1;
+          if (a.group_tile_start[mid + 1] > tile) hi = mid; else lo = mid + 1;
+        }
+        grp = lo;
+      }
       if (!valid) grp = 0;
       const GroupDesc &d = a.groups[grp];
       const unsigned local = tile - a.group_tile_start[grp];

@@ -540,4 +540,12 @@ void nvte_unswizzle_scaling_factors(const NVTETensor input, NVTETensor output, h
   });
 }
 
+void nvte_multi_tensor_unswizzle_scaling_factors(const NVTETensor *inputs, NVTETensor *outputs,
+                                                 const size_t num_tensors, hipStream_t stream) {
+  api_guard("nvte_multi_tensor_unswizzle_scaling_factors", [&] {
+    for (size_t i = 0; i < num_tensors; ++i)
+      swizzle_tensor(*lookup_checked(inputs[i]), *lookup_checked(outputs[i]), false, stream);
+  });
+}
+
 }  // extern "C"

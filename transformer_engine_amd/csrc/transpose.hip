@@ -237,4 +237,12 @@ void nvte_transpose_with_noop(const NVTETensor input, const NVTETensor noop, NVT
   });
 }
 
+void nvte_fp8_transpose_dbias(const NVTETensor input, NVTETensor transposed_output, NVTETensor dbias,
+                              NVTETensor workspace, hipStream_t stream) {
+  api_guard("nvte_fp8_transpose_dbias", [&] {
+    te::fp8_transpose_dbias_launch(*lookup_checked(input), *lookup_checked(transposed_output),
+                                   *lookup_checked(dbias), *lookup_checked(workspace), stream);
+  });
+}
+
 }  // extern "C"

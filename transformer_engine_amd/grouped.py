@@ -209,7 +209,7 @@ def general_grouped_gemm_for_grouped_tensor(A: Union[GroupedTensor, List[Float8T
                                             bias: Optional[GroupedTensor] = None,
                                             bias_scale: Optional[torch.Tensor] = None, grad: bool = False,
                                             alpha: Optional[torch.Tensor] = None,
-                                            beta: Optional[torch.Tensor] = None):
+                                            beta: Optional[torch.Tensor] = None, sm_count: int = 0):
     """ref pytorch/cpp_extensions/gemm.py:463-620.  ``A`` may be a list of per-expert weights
     (discrete in), ``out`` a list of per-expert buffers (discrete out, wgrad)."""
     assert layout in ("TN", "NN", "NT"), f"GEMM layout {layout} not supported."
@@ -233,6 +233,9 @@ def general_grouped_gemm_for_grouped_tensor(A: Union[GroupedTensor, List[Float8T
     cfg = api.nvte_create_grouped_matmul_config()
     b8 = C.c_uint8(1 if use_split_accumulator else 0)
     api.nvte_set_grouped_matmul_config_attribute(cfg, 4, C.byref(b8), 1)
+    if sm_count:
+        smc = C.c_int(int(sm_count))
+        api.nvte_set_grouped_matmul_config_attribute(cfg, 3, C.byref(smc), C.sizeof(smc))
     stream = current_stream_ptr()
     wb = B.wrap()
     tmp = [walpha, wbeta, wws]
