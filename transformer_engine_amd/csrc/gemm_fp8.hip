@@ -1208,8 +1208,10 @@ struct GroupedCall {
   size_t num_c = 0;
 };
 
+// `ws_ptr` / `ws_bytes`: device memory for the GroupDesc records + tile prefix (the caller's
+// workspace_setup, or this library's static scratch array for the entry point that allocates nothing).
 void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool transa, bool transb,
-                       const NVTETensor alpha_, const NVTETensor beta_, NVTETensor ws_setup_,
+                       const NVTETensor alpha_, const NVTETensor beta_, void *ws_ptr, size_t ws_bytes,
                        NVTEGroupedMatmulConfig config, hipStream_t stream) {
   NVTE_CHECK(G >= 1, "Grouped GEMM: number of tensors must be at least 1");
   NVTE_CHECK(G <= 1024, "Grouped GEMM: at most 1024 member tensors are supported, got ", G);
@@ -1303,11 +1305,9 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   }
   NVTE_CHECK(is_high_precision(d_dtype), "Grouped GEMM: D must be BF16, FP16, or FP32.");
 
-  Tensor &ws = *lookup_checked(ws_setup_);
-  const size_t ws_bytes = ws.data.numel() * dtype_bits(ws.data.dtype) / 8;
-  NVTE_CHECK(ws.data.ptr != nullptr && ws_bytes >= grouped_setup_bytes(G), "Grouped GEMM: Insufficient setup workspace (",
+  NVTE_CHECK(ws_ptr != nullptr && ws_bytes >= grouped_setup_bytes(G), "Grouped GEMM: Insufficient setup workspace (",
              ws_bytes, " bytes, need ", grouped_setup_bytes(G), ": nvte_get_grouped_gemm_setup_workspace_size)");
-  const uintptr_t ws_al = (reinterpret_cast<uintptr_t>(ws.data.ptr) + 255) & ~static_cast<uintptr_t>(255);
+  const uintptr_t ws_al = (reinterpret_cast<uintptr_t>(ws_ptr) + 255) & ~static_cast<uintptr_t>(255);
   GroupDesc *descs = reinterpret_cast<GroupDesc *>(ws_al);
   unsigned *tile_start = reinterpret_cast<unsigned *>(ws_al + round_up(G * sizeof(GroupDesc), 256));
 
@@ -1335,6 +1335,12 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
 }
 
+void ws_of(NVTETensor ws_setup_, void *&ptr, size_t &bytes) {
+  Tensor &ws = *lookup_checked(ws_setup_);
+  ptr = ws.data.ptr;
+  bytes = ws.data.numel() * dtype_bits(ws.data.dtype) / 8;
+}
+
 }  // namespace
 }  // namespace te
 
@@ -1343,60 +1349,6 @@ using namespace te;
 extern "C" {
 
 void nvte_cublas_handle_init(void) { api_enter("nvte_cublas_handle_init"); }
-
-void nvte_cublas_gemm(const NVTETensor A, const NVTETensor B, NVTETensor D, const NVTETensor bias,
-                      NVTETensor pre_gelu_out, bool transa, bool transb, bool grad,
-                      NVTETensor workspace, bool accumulate, bool use_split_accumulator,
-                      int math_sm_count, hipStream_t stream) {
-  api_guard("nvte_cublas_gemm", [&] {
-    (void)use_split_accumulator; (void)math_sm_count;
-    gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
-              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), 1.f, accumulate ? 1.f : 0.f,
-              stream);
-  });
-}
-
-void nvte_cublas_gemm_scaled(const NVTETensor A, const NVTETensor B, NVTETensor D,
-                             const NVTETensor bias, NVTETensor pre_gelu_out, bool transa,
-                             bool transb, bool grad, NVTETensor workspace, float alpha, float beta,
-                             bool use_split_accumulator, int math_sm_count, hipStream_t stream) {
-  api_guard("nvte_cublas_gemm_scaled", [&] {
-    (void)use_split_accumulator; (void)math_sm_count;
-    gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
-              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), alpha, beta, stream);
-  });
-}
-
-void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTETensor A,
-                         const NVTETensor B, const float *beta, const NVTETensor C, NVTETensor D,
-                         NVTETensor workspace, NVTEMatmulConfig config, hipStream_t stream) {
-  api_guard("nvte_cublas_gemm_v2", [&] {
-    const Tensor &a = *lookup_checked(A);
-    const Tensor &b = *lookup_checked(B);
-    const Tensor *c = lookup_checked(C);
-    Tensor *d = lookup_checked(D);
-    NVTE_CHECK(c == d, "Currently nvte_cublas_gemm_v2 does not support different C and D tensors.");
-    NVTE_CHECK(alpha != nullptr && beta != nullptr, "alpha and beta must be valid host pointers");
-    MatmulConfig cfg;
-    if (config != nullptr) cfg = *static_cast<const MatmulConfig *>(config);
-    const bool grad_epi = cfg.dbias_tensor != nullptr || cfg.with_dgelu_epilogue;
-    if (grad_epi) {
-      NVTE_CHECK(cfg.bias_tensor == nullptr && !cfg.with_gelu_epilogue, "Invalid epilogue (bias=",
-                 cfg.bias_tensor != nullptr, ", dbias=", cfg.dbias_tensor != nullptr,
-                 ", gelu=", cfg.with_gelu_epilogue, ", dgelu=", cfg.with_dgelu_epilogue, ").");
-    }
-    const Tensor *bias_t = nullptr;
-    if (!grad_epi && cfg.bias_tensor != nullptr) bias_t = lookup_checked(cfg.bias_tensor);
-    if (grad_epi && cfg.dbias_tensor != nullptr) bias_t = lookup_checked(cfg.dbias_tensor);
-    const Tensor *aux = nullptr;
-    if (cfg.with_gelu_epilogue || cfg.with_dgelu_epilogue) {
-      NVTE_CHECK(cfg.epilogue_aux_tensor != nullptr, "Requested epilogue without providing aux tensor.");
-      aux = lookup(cfg.epilogue_aux_tensor);
-    }
-    gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, lookup(workspace), *alpha, *beta,
-              stream);
-  });
-}
 
 size_t nvte_get_grouped_gemm_setup_workspace_size(size_t num_tensors) { return grouped_setup_bytes(num_tensors); }
 
@@ -1411,8 +1363,10 @@ void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedT
     call.B = lookup_grouped_checked(B);
     call.C = C ? lookup_grouped_checked(C) : nullptr;
     call.D = lookup_grouped_checked(D);
+    void *wp; size_t wb;
+    ws_of(workspace_setup, wp, wb);
     grouped_gemm_impl("nvte_grouped_gemm", call, call.A->num_tensors, transa != 0, transb != 0, alpha, beta,
-                      workspace_setup, config, stream);
+                      wp, wb, config, stream);
   });
 }
 
@@ -1432,8 +1386,10 @@ void nvte_grouped_gemm_with_discrete_inputA(const NVTETensor *A_list, size_t num
     call.D = lookup_grouped_checked(D);
     NVTE_CHECK(call.B->num_tensors == num_a_tensors, "Grouped GEMM: A_list must have num_tensors (",
                call.B->num_tensors, ") entries, got ", num_a_tensors);
+    void *wp; size_t wb;
+    ws_of(workspace_setup, wp, wb);
     grouped_gemm_impl("nvte_grouped_gemm_with_discrete_inputA", call, num_a_tensors, transa != 0, transb != 0,
-                      alpha, beta, workspace_setup, config, stream);
+                      alpha, beta, wp, wb, config, stream);
   });
 }
 
@@ -1460,8 +1416,10 @@ void nvte_grouped_gemm_with_discrete_out(const NVTEGroupedTensor A, int transa, 
     if (num_c_tensors > 0)
       NVTE_CHECK(num_c_tensors == G, "Grouped GEMM: C_list must have num_tensors (", G, ") entries, got ",
                  num_c_tensors);
+    void *wp; size_t wb;
+    ws_of(workspace_setup, wp, wb);
     grouped_gemm_impl("nvte_grouped_gemm_with_discrete_out", call, G, transa != 0, transb != 0, alpha, beta,
-                      workspace_setup, config, stream);
+                      wp, wb, config, stream);
   });
 }
 
@@ -1473,22 +1431,18 @@ void nvte_multi_tensor_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor
   api_guard("nvte_multi_tensor_gemm", [&] {
     (void)use_split_accumulator; (void)math_sm_count;
     if (num_gemms <= 0) return;
-    // Independent GEMMs fanned over the compute-stream pool and joined on `stream`
-    // (ref cublaslt_gemm.cu:970-1023).
-    const int ns = std::min(num_gemms, nvte_get_num_compute_streams());
-    hipEvent_t e0 = nvte_get_compute_stream_event(0);
-    NVTE_CHECK_HIP(hipEventRecord(e0, stream));
-    for (int s = 0; s < ns; ++s) NVTE_CHECK_HIP(hipStreamWaitEvent(nvte_get_compute_stream(s), e0, 0));
+    // The reference fans the list over 4 side streams with event fork / join because one cuBLAS GEMM
+    // of an expert-sized problem does not fill an H100 (ref cublaslt_gemm.cu:970-1023).  Here every
+    // member is a persistent launch that already spreads over all 256 CUs (a member smaller than the
+    // chip leaves CUs to the next launch: launches of one stream overlap at their tails), so the list
+    // runs in order on the CALLER's stream: no cross-stream events on the hot path, nothing to join,
+    // and capturable in a HIP graph as a plain chain.  (The side-stream version hung intermittently on
+    // this pool's boxes - 4 hardware queues per process shared with the framework's own streams.)
     for (int i = 0; i < num_gemms; ++i) {
       gemm_impl(*lookup_checked(A[i]), *lookup_checked(B[i]), *lookup_checked(D[i]),
                 bias ? lookup(bias[i]) : nullptr, pre_gelu_out ? lookup(pre_gelu_out[i]) : nullptr,
                 transa, transb, grad, workspace ? lookup(workspace[i % nvte_get_num_compute_streams()]) : nullptr,
-                1.f, accumulate ? 1.f : 0.f, nvte_get_compute_stream(i % nvte_get_num_compute_streams()));
-    }
-    for (int s = 0; s < ns; ++s) {
-      hipEvent_t e = nvte_get_compute_stream_event(s);
-      NVTE_CHECK_HIP(hipEventRecord(e, nvte_get_compute_stream(s)));
-      NVTE_CHECK_HIP(hipStreamWaitEvent(stream, e, 0));
+                1.f, accumulate ? 1.f : 0.f, stream);
     }
   });
 }

@@ -138,20 +138,11 @@ void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
                                 const NVTEQuantizationConfig quant_config, const size_t num_tensors,
                                 hipStream_t stream) {
   api_guard("nvte_multi_tensor_quantize", [&] {
-    if (num_tensors == 0) return;
-    // Fork over the compute-stream pool, join back on `stream` (ref cast.cu:65-88).
-    StreamPool &p = pool();
-    const int used = static_cast<int>(std::min<size_t>(num_tensors, kNumStreams));
-    NVTE_CHECK_HIP(hipEventRecord(p.e[0], stream));
-    for (int s = 0; s < used; ++s) NVTE_CHECK_HIP(hipStreamWaitEvent(p.s[s], p.e[0], 0));
-    for (size_t i = 0; i < num_tensors; ++i) {
-      with_config(inputs[i], outputs[i], static_cast<const QuantConfig *>(quant_config),
-                  p.s[i % kNumStreams]);
-    }
-    for (int s = 0; s < used; ++s) {
-      NVTE_CHECK_HIP(hipEventRecord(p.e[s], p.s[s]));
-      NVTE_CHECK_HIP(hipStreamWaitEvent(stream, p.e[s], 0));
-    }
+    // In order on the caller's stream (the reference forks over 4 side streams, ref cast.cu:65-88):
+    // every quantize kernel here is a full-chip HBM-bound launch, so side streams add event traffic
+    // and nothing else; see nvte_multi_tensor_gemm.
+    for (size_t i = 0; i < num_tensors; ++i)
+      with_config(inputs[i], outputs[i], static_cast<const QuantConfig *>(quant_config), stream);
   });
 }
 

@@ -195,7 +195,7 @@ def general_grouped_gemm(A, B, out, out_dtype, layout: str = "TN", m_splits=None
                          accumulate: bool = False, grad: bool = False,
                          use_split_accumulator: bool = False, single_output: bool = False):
     """List form (ref pytorch/cpp_extensions/gemm.py:277 -> nvte_multi_tensor_gemm): independent
-    GEMMs fanned over the library's compute-stream pool."""
+    GEMMs, each a persistent full-chip launch, in order on the current stream."""
     assert layout in ("TN", "NN", "NT")
     transa, transb = layout[0] == "T", layout[1] == "T"
     n = len(A)
