@@ -106,6 +106,18 @@ void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedT
                        const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
                        const NVTETensor beta, NVTETensor workspace_setup, NVTETensor workspace_cublas,
                        NVTEGroupedMatmulConfig config, hipStream_t stream);
+/* NO counterpart in the reference.  nvte_grouped_gemm for callers that cannot allocate device memory
+ * or carry a workspace: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same arguments minus the two workspaces: the per-member records + tile prefix live in a
+ * static device array of this library (about 17 KiB per GPU, held until the process ends) whose
+ * address is resolved once per device (at nvte_cublas_handle_init() or at the first call on that
+ * device).  The call allocates nothing.  Limits: at most nvte_amd_grouped_gemm_noalloc_max_tensors()
+ * (256) member tensors, more is an error; every call on a GPU shares that GPU's array, so two calls
+ * that overlap on one GPU (different streams) race - serialise them or use nvte_grouped_gemm. */
+void nvte_amd_grouped_gemm_noalloc(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
+                                   const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
+                                   const NVTETensor beta, NVTEGroupedMatmulConfig config, hipStream_t stream);
+size_t nvte_amd_grouped_gemm_noalloc_max_tensors(void);
 /* ref gemm.h:415.  A given as a list of (same-shape or not) per-expert weight tensors. */
 void nvte_grouped_gemm_with_discrete_inputA(const NVTETensor *A_list, size_t num_a_tensors, int transa,
                                             const NVTEGroupedTensor B, int transb, const NVTEGroupedTensor C,

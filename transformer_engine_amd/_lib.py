@@ -173,6 +173,8 @@ _SIGS = {
     "nvte_convert_int32_to_int64_with_multiplier": (_V, [_P, _P, _SZ, C.c_int64, _P]),
     "nvte_compute_grouped_tensor_offsets": (_V, [_P, _P, _SZ, C.c_int64, _P]),
     "nvte_grouped_gemm": (_V, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nvte_amd_grouped_gemm_noalloc": (_V, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "nvte_amd_grouped_gemm_noalloc_max_tensors": (_SZ, []),
     "nvte_grouped_gemm_with_discrete_inputA": (_V, [C.POINTER(_P), _SZ, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nvte_grouped_gemm_with_discrete_out": (_V, [_P, _I, _P, _I, C.POINTER(_P), _SZ, C.POINTER(_P), _SZ, _P, _P,
                                                  _P, _P, _P, _P]),

@@ -1335,6 +1335,35 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
 }
 
+// ---- static scratch for nvte_amd_grouped_gemm_noalloc (amd_ext.h) --------------------------------
+// The GroupDesc records + tile prefix of ONE grouped launch of up to kNoAllocMaxGroups members live in
+// a device array of this code object instead of a caller workspace.  Every GPU the library runs on
+// holds its own copy (about 17 KiB) until the process ends.  The array's name is a host-side stand-in:
+// host code only ever uses the per-device address obtained below.
+constexpr size_t kNoAllocMaxGroups = 256;
+constexpr size_t kNoAllocScratchBytes = 256 * 64 /* >= round_up(256 * sizeof(GroupDesc), 256) */ + (256 + 1) * 4 + 256 + 256;
+static_assert(sizeof(GroupDesc) <= 64, "resize kNoAllocScratchBytes");
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex scratch_mu;
+void *scratch_ptr_of_device[kMaxDevices] = {};
+
+// Device address of `scratch` on the CURRENT device (looked up once per device).
+void *scratch_ptr() {
+  int dev = 0;
+  NVTE_CHECK_HIP(hipGetDevice(&dev));
+  NVTE_CHECK(dev >= 0 && dev < kMaxDevices, "device ordinal out of range");
+  std::lock_guard<std::mutex> g(scratch_mu);
+  if (scratch_ptr_of_device[dev] == nullptr) {
+    void *p = nullptr;
+    NVTE_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    NVTE_CHECK(p != nullptr, "hipGetSymbolAddress returned a null address for the static scratch array");
+    scratch_ptr_of_device[dev] = p;
+  }
+  return scratch_ptr_of_device[dev];
+}
+
 void ws_of(NVTETensor ws_setup_, void *&ptr, size_t &bytes) {
   Tensor &ws = *lookup_checked(ws_setup_);
   ptr = ws.data.ptr;
@@ -1348,7 +1377,88 @@ using namespace te;
 
 extern "C" {
 
-void nvte_cublas_handle_init(void) { api_enter("nvte_cublas_handle_init"); }
+// No BLAS handle exists here; the call is the library's per-device set-up point: it resolves the
+// address of the static scratch array on the current device (so that a later
+// nvte_amd_grouped_gemm_noalloc under graph capture does not have to).
+void nvte_cublas_handle_init(void) {
+  api_guard("nvte_cublas_handle_init", [&] { (void)scratch_ptr(); });
+}
+
+size_t nvte_amd_grouped_gemm_noalloc_max_tensors(void) { return kNoAllocMaxGroups; }
+
+void nvte_amd_grouped_gemm_noalloc(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
+                                   const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
+                                   const NVTETensor beta, NVTEGroupedMatmulConfig config, hipStream_t stream) {
+  api_guard("nvte_amd_grouped_gemm_noalloc", [&] {
+    GroupedCall call;
+    call.A = lookup_grouped_checked(A);
+    call.B = lookup_grouped_checked(B);
+    call.C = C ? lookup_grouped_checked(C) : nullptr;
+    call.D = lookup_grouped_checked(D);
+    const size_t G = call.A->num_tensors;
+    NVTE_CHECK(G <= kNoAllocMaxGroups, "nvte_amd_grouped_gemm_noalloc: ", G, " member tensors exceed the static scratch "
+               "limit of ", kNoAllocMaxGroups, "; use nvte_grouped_gemm with a caller workspace");
+    static_assert(kNoAllocScratchBytes >= 256 * 64 + (kNoAllocMaxGroups + 1) * sizeof(unsigned) + 256, "scratch too small");
+    // Nothing in the scratch has to start at zero: grouped_setup_kernel rewrites every record and
+    // prefix entry of this call's G members before the GEMM kernel (same stream) reads them.
+    grouped_gemm_impl("nvte_amd_grouped_gemm_noalloc", call, G, transa != 0, transb != 0, alpha, beta,
+                      scratch_ptr(), kNoAllocScratchBytes, config, stream);
+  });
+}
+
+void nvte_cublas_gemm(const NVTETensor A, const NVTETensor B, NVTETensor D, const NVTETensor bias,
+                      NVTETensor pre_gelu_out, bool transa, bool transb, bool grad,
+                      NVTETensor workspace, bool accumulate, bool use_split_accumulator,
+                      int math_sm_count, hipStream_t stream) {
+  api_guard("nvte_cublas_gemm", [&] {
+    (void)use_split_accumulator; (void)math_sm_count;
+    gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
+              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), 1.f, accumulate ? 1.f : 0.f,
+              stream);
+  });
+}
+
+void nvte_cublas_gemm_scaled(const NVTETensor A, const NVTETensor B, NVTETensor D,
+                             const NVTETensor bias, NVTETensor pre_gelu_out, bool transa,
+                             bool transb, bool grad, NVTETensor workspace, float alpha, float beta,
+                             bool use_split_accumulator, int math_sm_count, hipStream_t stream) {
+  api_guard("nvte_cublas_gemm_scaled", [&] {
+    (void)use_split_accumulator; (void)math_sm_count;
+    gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
+              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), alpha, beta, stream);
+  });
+}
+
+void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTETensor A,
+                         const NVTETensor B, const float *beta, const NVTETensor C, NVTETensor D,
+                         NVTETensor workspace, NVTEMatmulConfig config, hipStream_t stream) {
+  api_guard("nvte_cublas_gemm_v2", [&] {
+    const Tensor &a = *lookup_checked(A);
+    const Tensor &b = *lookup_checked(B);
+    const Tensor *c = lookup_checked(C);
+    Tensor *d = lookup_checked(D);
+    NVTE_CHECK(c == d, "Currently nvte_cublas_gemm_v2 does not support different C and D tensors.");
+    NVTE_CHECK(alpha != nullptr && beta != nullptr, "alpha and beta must be valid host pointers");
+    MatmulConfig cfg;
+    if (config != nullptr) cfg = *static_cast<const MatmulConfig *>(config);
+    const bool grad_epi = cfg.dbias_tensor != nullptr || cfg.with_dgelu_epilogue;
+    if (grad_epi) {
+      NVTE_CHECK(cfg.bias_tensor == nullptr && !cfg.with_gelu_epilogue, "Invalid epilogue (bias=",
+                 cfg.bias_tensor != nullptr, ", dbias=", cfg.dbias_tensor != nullptr,
+                 ", gelu=", cfg.with_gelu_epilogue, ", dgelu=", cfg.with_dgelu_epilogue, ").");
+    }
+    const Tensor *bias_t = nullptr;
+    if (!grad_epi && cfg.bias_tensor != nullptr) bias_t = lookup_checked(cfg.bias_tensor);
+    if (grad_epi && cfg.dbias_tensor != nullptr) bias_t = lookup_checked(cfg.dbias_tensor);
+    const Tensor *aux = nullptr;
+    if (cfg.with_gelu_epilogue || cfg.with_dgelu_epilogue) {
+      NVTE_CHECK(cfg.epilogue_aux_tensor != nullptr, "Requested epilogue without providing aux tensor.");
+      aux = lookup(cfg.epilogue_aux_tensor);
+    }
+    gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, lookup(workspace), *alpha, *beta,
+              stream);
+  });
+}
 
 size_t nvte_get_grouped_gemm_setup_workspace_size(size_t num_tensors) { return grouped_setup_bytes(num_tensors); }
 
