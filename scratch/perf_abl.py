@@ -1,23 +1,62 @@
-import sys; sys.path.insert(0, '.')
-import os, torch
-from transformer_engine_amd.tensor import *
-from transformer_engine_amd.gemm import general_gemm
-def timeit(fn, it=20):
-    for _ in range(3): fn()
+"""Ablations on the stamps build (fprop shape, E4M3 x E4M3): per-variant kernel time, in-kernel clock, steady K-tile interval."""
+import os, sys, ctypes as C, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("TE_AMD_LIBRARY", os.path.join(ROOT, "scratch", "lib_stamps", "libtransformer_engine.so"))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from transformer_engine_amd import _lib, general_gemm
+from transformer_engine_amd.tensor import DType, Float8CurrentScalingQuantizer
+tok, hid, ffn = 8192, 4096, 14336
+g = torch.Generator(device="cuda").manual_seed(1234)
+x = torch.randn(tok, hid, device="cuda", dtype=torch.bfloat16, generator=g)
+w = (torch.randn(ffn, hid, device="cuda", dtype=torch.float32, generator=g) * 0.02).to(torch.bfloat16)
+E4 = DType.kFloat8E4M3
+x8, w8 = Float8CurrentScalingQuantizer(E4, "cuda")(x), Float8CurrentScalingQuantizer(E4, "cuda")(w)
+out = torch.empty((tok, ffn), dtype=torch.bfloat16, device="cuda")
+fn = lambda: general_gemm(w8, x8, layout="TN", out=out)
+lib = _lib.raw_lib
+lib.nvte_amd_debug_set_gemm_stamps.argtypes = [C.c_void_p]
+SL = 512
+stamps = torch.zeros(256 * SL, dtype=torch.int64, device="cuda")
+t0 = time.time()
+while time.time() - t0 < 1.0:
+    for _ in range(20): fn()
     torch.cuda.synchronize()
+names = {106: "L2 prefetch 4 K tiles ahead", 105: "late staging waves 4-7", 0: "full", 101: "no global->LDS", 102: "no LDS reads", 103: "MFMA+barrier only", 104: "full, L2-hot (12 panels)"}
+VARS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 101, 102, 103, 104]
+os.environ["TE_GEMM_DBG"] = "0"; fn(); torch.cuda.synchronize(); ref = out.clone()
+for v in VARS:
+    if v in (0, 105, 106):
+        os.environ["TE_GEMM_DBG"] = str(v); out.zero_(); fn(); torch.cuda.synchronize()
+        print("variant", v, "output equals full:", torch.equal(out, ref), flush=True)
+for rnd in range(int(os.environ.get("ROUNDS", "2"))):
+  for v in VARS:
+    os.environ["TE_GEMM_DBG"] = str(v)
+    for _ in range(30): fn()      # settle the clock for this variant
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(it): fn()
+    for _ in range(20): fn()
     e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / it
-def q8(x, dt=DType.kFloat8E4M3):
-    q = Float8Quantizer(torch.ones(1, device="cuda"), torch.zeros(1, device="cuda"), dt)
-    return q(x)
-tok, hid, ffn = 8192, 4096, 14336
-x = q8(torch.randn(tok, hid, device="cuda", dtype=torch.bfloat16))
-w = q8(torch.randn(ffn, hid, device="cuda", dtype=torch.bfloat16))
-dy = q8(torch.randn(tok, ffn, device="cuda", dtype=torch.bfloat16))
-fl = 2 * tok * hid * ffn
-t1 = timeit(lambda: general_gemm(w, x, out_dtype=torch.bfloat16, layout="TN"))
-t2 = timeit(lambda: general_gemm(w, dy, out_dtype=torch.bfloat16, layout="NN"))
-print("ABL", os.environ.get("NVTE_AMD_GEMM_ABLATE", "0"), f"fprop(K=4096) {t1*1e3:.0f} us {fl/t1/1e9:.0f} TF | dgrad(K=14336) {t2*1e3:.0f} us {fl/t2/1e9:.0f} TF")
+    ms = s.elapsed_time(e) / 20
+    if os.environ.get("COLD"):
+        flush = torch.empty(640 * 1024 * 1024, dtype=torch.uint8, device="cuda")
+        evs = []
+        for i in range(12):
+            flush.fill_(i)
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(); fn(); b_.record(); evs.append((a_, b_))
+        torch.cuda.synchronize()
+        cold = sorted(a_.elapsed_time(b_) for a_, b_ in evs[2:])
+        print(f"   cold-cache launches (640 MB written before each): median {cold[len(cold)//2]*1000:.1f} us min {cold[0]*1000:.1f}", flush=True)
+        del flush
+    lib.nvte_amd_debug_set_gemm_stamps(C.c_void_p(stamps.data_ptr()))
+    fn(); fn(); torch.cuda.synchronize()
+    lib.nvte_amd_debug_set_gemm_stamps(None)
+    st = stamps.cpu().numpy().reshape(256, SL)
+    n = int(st[0, SL - 4]); t = st[:, :n].astype(np.float64) * 10.0
+    clk = (st[:, SL - 2] - st[:, SL - 1]).astype(np.float64) / ((t[:, n - 1] - t[:, 0]))
+    per = 34
+    iv = np.diff(t, axis=1)
+    steady = np.mean([iv[:, 1 + c * per + 8: 1 + c * per + 31].mean() for c in range(1, 6)]) / 1000
+    tot = (t[:, n - 1] - t[:, 0]) / 1000
+    print(f"{names[v]:28s} {ms*1000:7.1f} us  {2*tok*hid*ffn/ms/1e9:6.0f} TF  clock {np.median(clk):.3f} GHz  K-tile {steady:.3f} us = {steady*np.median(clk)*1000:.0f} cyc  WG total min/med/max {tot.min():.0f}/{np.median(tot):.0f}/{tot.max():.0f}", flush=True)

@@ -15,7 +15,8 @@ import os
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtransformer_engine.so")
+# TE_AMD_LIBRARY: load another build of the same library (diagnostic builds under scratch/)
+LIB_PATH = os.environ.get("TE_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libtransformer_engine.so")
 
 # ---- enums (ABI values, include/transformer_engine/transformer_engine.h) -------------
 kByte, kInt16, kInt32, kInt64, kFloat32, kFloat16, kBFloat16, kFloat8E4M3, kFloat8E5M2, kFloat8E8M0, kFloat4E2M1 = range(11)
