@@ -19,6 +19,8 @@
 // (see DESIGN.md for the bank arithmetic).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "device_utils.h"
 
@@ -28,76 +30,111 @@ namespace {
 constexpr int kTile = 128;      // tile edge, elements
 constexpr int kCtThreads = 256;
 
-// ---------------------------------------------------------------- aligned 128x128 tile kernel
-// Requires rows % 128 == 0, cols % 128 == 0, 16-byte aligned base pointers.
+// ---------------------------------------------------------------- 128x128 tile kernel, persistent
+// Requires cols % 8 == 0, rows % 16 == 0 and 16-byte aligned base pointers (every 16-byte load, 8-byte
+// rowwise store and 16-byte transposed store is then aligned); GUARD = false additionally requires whole
+// tiles (rows % 128 == 0, cols % 128 == 0) and drops every bounds check.
+// Persistent: the grid is a few workgroups per CU and workgroup w walks tiles w, w + grid, ...  The eight
+// 16-byte loads of the NEXT tile are issued before the current tile is converted, stored and pushed
+// through LDS, so a workgroup always has a tile's worth of loads in flight (a one-tile workgroup spends
+// its life waiting: load -> convert -> barrier -> store), the LDS image is double-buffered (one barrier
+// per tile) and amax costs one atomic per workgroup instead of one per tile.
 // DBIAS: additionally leaves the tile's column sums (over its 128 rows, of the UNSCALED input) in
 // dbias_part[tile_r][col] - the [ceil(R/128), C] fp32 workspace of nvte_quantize_dbias, reduced by
 // dbias.hip afterwards: cast, transpose and bias gradient from ONE read of dY.
-template <typename IT, Fp8 F, bool DBIAS = false>
+template <typename IT, Fp8 F, bool DBIAS = false, bool GUARD = false>
 __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
     const IT *__restrict__ in, const float *__restrict__ noop, uint8_t *__restrict__ out_c,
     uint8_t *__restrict__ out_t, const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
     float *__restrict__ scale_inv_ptr, const size_t rows, const size_t cols, const unsigned tiles_c,
-    float *__restrict__ dbias_part = nullptr) {
+    const unsigned ntiles, float *__restrict__ dbias_part = nullptr) {
   if (noop_set(noop)) return;
 
-  __shared__ __attribute__((aligned(16))) uint8_t tile_t[kTile * kTile];
+  __shared__ __attribute__((aligned(16))) uint8_t tile_t[2][kTile * kTile];
   __shared__ float red[kCtThreads / kWave];
-  __shared__ float colpart[DBIAS ? 16 : 1][kTile];
+  __shared__ float colpart[DBIAS ? 2 : 1][DBIAS ? 16 : 1][kTile];
 
   const unsigned t = threadIdx.x;
   const unsigned cg = t & 15u;   // 8-column group
   const unsigned rg = t >> 4;    // 8-row group
-  const size_t tile_r = blockIdx.x / tiles_c;
-  const size_t tile_col = blockIdx.x % tiles_c;
-  const size_t row0 = tile_r * kTile + rg * 8;
-  const size_t col0 = tile_col * kTile + cg * 8;
-
   const float scale = scale_ptr ? *scale_ptr : 1.0f;
   float amax = 0.f;
 
-  // q[i][h]: row i of this thread's block, columns 4h..4h+3
-  uint32_t q[8][2];
-  {
-    float f[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) Load8<IT>::run(in + (row0 + i) * cols + col0, f[i]);
+  auto load_tile = [&](unsigned tile, Raw8<IT> (&raw)[8]) {
+    const size_t row0 = static_cast<size_t>(tile / tiles_c) * kTile + rg * 8;
+    const size_t col0 = static_cast<size_t>(tile % tiles_c) * kTile + cg * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if (!GUARD || (col0 < cols && row0 + i < rows))
+        raw[i] = Raw8<IT>::load(in + (row0 + i) * cols + col0);
+      else
+        raw[i] = Raw8<IT>::zero();
+    }
+  };
+
+  Raw8<IT> cur[8], nxt[8];
+  unsigned tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile, cur);
+  for (unsigned it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    const unsigned next = tile + gridDim.x;
+    if (next < ntiles) load_tile(next, nxt);   // in flight while this tile is processed
+
+    const size_t tile_r = tile / tiles_c, tile_col = tile % tiles_c;
+    const size_t row0 = tile_r * kTile + rg * 8;
+    const size_t col0 = tile_col * kTile + cg * 8;
+    const unsigned buf = it & 1u;
+
+    // q[i][h]: row i of this thread's block, columns 4h..4h+3
+    uint32_t q[8][2];
+    float csum[DBIAS ? 8 : 1];
+    if constexpr (DBIAS) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, __builtin_fabsf(f[i][j]));
-      q[i][0] = cvt4_fp8<F>(f[i][0] * scale, f[i][1] * scale, f[i][2] * scale, f[i][3] * scale);
-      q[i][1] = cvt4_fp8<F>(f[i][4] * scale, f[i][5] * scale, f[i][6] * scale, f[i][7] * scale);
+      for (int j = 0; j < 8; ++j) csum[j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float f[8];
+      cur[i].widen8(f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, __builtin_fabsf(f[j]));
+      q[i][0] = cvt4_fp8<F>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+      q[i][1] = cvt4_fp8<F>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+      if constexpr (DBIAS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) csum[j] += f[j];
+      }
+      // rowwise output straight from registers
+      if (!GUARD || (col0 < cols && row0 + i < rows)) {
+        u32x2 v = {q[i][0], q[i][1]};
+        *reinterpret_cast<u32x2 *>(out_c + (row0 + i) * cols + col0) = v;
+      }
     }
     if constexpr (DBIAS) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 8; ++j) colpart[buf][rg][cg * 8 + j] = csum[j];
+    }
+
+    // transposed output through the LDS image (device_utils.h); holds this tile's only barrier
+    if constexpr (GUARD) {
+      const size_t rows_left = rows - tile_r * kTile, cols_left = cols - tile_col * kTile;
+      store_tile_transposed<true>(tile_t[buf], q, t, out_t + (tile_col * kTile) * rows + tile_r * kTile, rows,
+                                  static_cast<unsigned>(rows_left >= kTile ? 8 : rows_left / 16),
+                                  static_cast<unsigned>(cols_left >= kTile ? kTile : cols_left));
+    } else {
+      store_tile_transposed(tile_t[buf], q, t, out_t + (tile_col * kTile) * rows + tile_r * kTile, rows);
+    }
+
+    if constexpr (DBIAS) {
+      // colpart[buf] was written before the barrier inside store_tile_transposed
+      if (t < kTile && (!GUARD || tile_col * kTile + t < cols)) {
         float c = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c += f[i][j];
-        colpart[rg][cg * 8 + j] = c;
+        for (int r = 0; r < 16; ++r) c += colpart[buf][r][t];
+        dbias_part[tile_r * cols + tile_col * kTile + t] = c;
       }
     }
-  }
-
-  // rowwise output straight from registers
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    u32x2 v = {q[i][0], q[i][1]};
-    *reinterpret_cast<u32x2 *>(out_c + (row0 + i) * cols + col0) = v;
-  }
-
-  // transposed output through the LDS image (device_utils.h)
-  store_tile_transposed(tile_t, q, t, out_t + (tile_col * kTile) * rows + tile_r * kTile, rows);
-
-  if constexpr (DBIAS) {
-    // colpart was written before the barrier inside store_tile_transposed
-    if (t < kTile) {
-      float c = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c += colpart[r][t];
-      dbias_part[tile_r * cols + tile_col * kTile + t] = c;
-    }
+    for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
   }
 
   if (amax_ptr != nullptr) {
@@ -284,19 +321,42 @@ void launch_general_by_out(const Tensor &in, const float *noop, Tensor &out, boo
   }
 }
 
-template <typename IT, Fp8 F>
-void launch_tile(const Tensor &in, const float *noop, Tensor &out, size_t rows, size_t cols,
+// Workgroups per CU of the persistent tile kernel (LDS: 32 KiB each; more resident workgroups = more
+// loads in flight, fewer = longer-lived workgroups).  NVTE_AMD_CT_WGS_PER_CU overrides (tuning aid).
+unsigned ct_grid(size_t ntiles) {
+  static const unsigned per_cu = [] {
+    const char *e = std::getenv("NVTE_AMD_CT_WGS_PER_CU");
+    const int v = e ? std::atoi(e) : 0;
+    return static_cast<unsigned>(v >= 1 && v <= 16 ? v : 4);
+  }();
+  return static_cast<unsigned>(std::min<size_t>(ntiles, static_cast<size_t>(device_info().num_cus) * per_cu));
+}
+
+template <typename IT, Fp8 F, bool DBIAS>
+void launch_tile(const Tensor &in, const float *noop, Tensor &out, size_t rows, size_t cols, float *part,
                  hipStream_t stream) {
-  const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
-  const size_t nblk = (rows / kTile) * tiles_c;
-  NVTE_CHECK(nblk < (1ull << 31), "tensor too large for the tile cast kernel");
-  hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, F>), dim3(nblk), dim3(kCtThreads), 0, stream,
-                     static_cast<const IT *>(in.data.ptr), noop,
-                     static_cast<uint8_t *>(out.data.ptr),
-                     static_cast<uint8_t *>(out.columnwise_data.ptr),
-                     static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
-                     static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c);
+  const unsigned tiles_c = static_cast<unsigned>(ceil_div(cols, kTile));
+  const size_t ntiles = ceil_div(rows, kTile) * tiles_c;
+  NVTE_CHECK(ntiles < (1ull << 31), "tensor too large for the tile cast kernel");
+  const bool whole = rows % kTile == 0 && cols % kTile == 0;
+  const dim3 grid(ct_grid(ntiles)), block(kCtThreads);
+#define TE_CT_ARGS                                                                                        \
+  static_cast<const IT *>(in.data.ptr), noop, static_cast<uint8_t *>(out.data.ptr),                      \
+      static_cast<uint8_t *>(out.columnwise_data.ptr), static_cast<const float *>(out.scale.ptr),        \
+      static_cast<float *>(out.amax.ptr), static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c,  \
+      static_cast<unsigned>(ntiles), part
+  if (whole)
+    hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, F, DBIAS, false>), grid, block, 0, stream, TE_CT_ARGS);
+  else
+    hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, F, DBIAS, true>), grid, block, 0, stream, TE_CT_ARGS);
+#undef TE_CT_ARGS
   NVTE_CHECK_HIP(hipGetLastError());
+}
+
+// Shapes the vector tile kernel takes: every 16-byte load / 8-byte rowwise store / 16-byte transposed store aligned.
+bool tile_path_ok(const Tensor &in, const Tensor &out, size_t rows, size_t cols) {
+  return is_fp8(out.data.dtype) && cols % 8 == 0 && rows % 16 == 0 && aligned16(in.data.ptr) &&
+         aligned16(out.data.ptr) && aligned16(out.columnwise_data.ptr);
 }
 
 template <typename IT, Fp8 F>
@@ -373,15 +433,13 @@ void cast_transpose_launch(const Tensor &in, const float *noop, Tensor &out, hip
   NVTE_REQUIRE_DATA(out.data, "cast_transpose output");
   NVTE_REQUIRE_DATA(out.columnwise_data, "cast_transpose transposed output");
 
-  const bool fp8_out = is_fp8(out.data.dtype);
-  const bool fast = fp8_out && rows % kTile == 0 && cols % kTile == 0 && aligned16(in.data.ptr) &&
-                    aligned16(out.data.ptr) && aligned16(out.columnwise_data.ptr);
+  const bool fast = tile_path_ok(in, out, rows, cols);
   TE_SWITCH_IN(in.data.dtype, IT, {
     if (fast) {
       if (out.data.dtype == kNVTEFloat8E4M3)
-        launch_tile<IT, Fp8::E4M3>(in, noop, out, rows, cols, stream);
+        launch_tile<IT, Fp8::E4M3, false>(in, noop, out, rows, cols, nullptr, stream);
       else
-        launch_tile<IT, Fp8::E5M2>(in, noop, out, rows, cols, stream);
+        launch_tile<IT, Fp8::E5M2, false>(in, noop, out, rows, cols, nullptr, stream);
     } else {
       launch_general_by_out<IT>(in, noop, out, true, rows, cols, stream);
     }
@@ -392,28 +450,15 @@ void cast_transpose_launch(const Tensor &in, const float *noop, Tensor &out, hip
 // the general fused kernel of activation.hip instead.  `part` = [rows/128, cols] fp32.
 bool cast_transpose_dbias_tile_launch(const Tensor &in, Tensor &out, float *part, hipStream_t stream) {
   const size_t rows = in.rows(), cols = in.cols();
-  if (!(is_fp8(out.data.dtype) && out.has_data() && out.has_columnwise_data() && rows % kTile == 0 &&
-        cols % kTile == 0 && rows > 0 && cols > 0 && aligned16(in.data.ptr) && aligned16(out.data.ptr) &&
-        aligned16(out.columnwise_data.ptr)))
+  if (!(out.has_data() && out.has_columnwise_data() && rows > 0 && cols > 0 && tile_path_ok(in, out, rows, cols)))
     return false;
-  const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
-  const size_t nblk = (rows / kTile) * tiles_c;
-  if (nblk >= (1ull << 31)) return false;
+  if (ceil_div(rows, kTile) * ceil_div(cols, kTile) >= (1ull << 31)) return false;
   TE_SWITCH_IN(in.data.dtype, IT, {
     if (out.data.dtype == kNVTEFloat8E4M3)
-      hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, Fp8::E4M3, true>), dim3(nblk), dim3(kCtThreads), 0, stream,
-                         static_cast<const IT *>(in.data.ptr), static_cast<const float *>(nullptr),
-                         static_cast<uint8_t *>(out.data.ptr), static_cast<uint8_t *>(out.columnwise_data.ptr),
-                         static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
-                         static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c, part);
+      launch_tile<IT, Fp8::E4M3, true>(in, nullptr, out, rows, cols, part, stream);
     else
-      hipLaunchKernelGGL((cast_transpose_tile_kernel<IT, Fp8::E5M2, true>), dim3(nblk), dim3(kCtThreads), 0, stream,
-                         static_cast<const IT *>(in.data.ptr), static_cast<const float *>(nullptr),
-                         static_cast<uint8_t *>(out.data.ptr), static_cast<uint8_t *>(out.columnwise_data.ptr),
-                         static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
-                         static_cast<float *>(out.scale_inv.ptr), rows, cols, tiles_c, part);
+      launch_tile<IT, Fp8::E5M2, true>(in, nullptr, out, rows, cols, part, stream);
   });
-  NVTE_CHECK_HIP(hipGetLastError());
   return true;
 }
 

@@ -258,6 +258,48 @@ __device__ __forceinline__ void store_tile_transposed(uint8_t *tile_t, uint32_t 
 __device__ __forceinline__ bool noop_set(const float *noop) { return noop != nullptr && noop[0] == 1.0f; }
 
 // ------------------------------------------------------------------ 8-element streaming loads -> fp32
+// Raw8: the same 8 elements kept as loaded (no arithmetic), so that a software-pipelined kernel can issue
+// the NEXT tile's loads before it touches the current tile's values.
+template <typename IT>
+struct Raw8;
+template <>
+struct Raw8<bf16_t> {
+  u32x4 v;
+  static __device__ __forceinline__ Raw8 zero() { return Raw8{u32x4{0u, 0u, 0u, 0u}}; }
+  static __device__ __forceinline__ Raw8 load(const bf16_t *p) { return Raw8{ld_stream<u32x4>(p)}; }
+  __device__ __forceinline__ void widen8(float (&f)[8]) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[2 * k] = __uint_as_float(v[k] << 16);
+      f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
+    }
+  }
+};
+template <>
+struct Raw8<f16_t> {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  h8 v;
+  static __device__ __forceinline__ Raw8 zero() { return Raw8{h8{0, 0, 0, 0, 0, 0, 0, 0}}; }
+  static __device__ __forceinline__ Raw8 load(const f16_t *p) { return Raw8{ld_stream<h8>(p)}; }
+  __device__ __forceinline__ void widen8(float (&f)[8]) const {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(v[k]);
+  }
+};
+template <>
+struct Raw8<float> {
+  f32x4 a, b;
+  static __device__ __forceinline__ Raw8 zero() { return Raw8{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}; }
+  static __device__ __forceinline__ Raw8 load(const float *p) { return Raw8{ld_stream<f32x4>(p), ld_stream<f32x4>(p + 4)}; }
+  __device__ __forceinline__ void widen8(float (&f)[8]) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] = a[k];
+      f[4 + k] = b[k];
+    }
+  }
+};
+
 template <typename IT>
 struct Load8;
 
