@@ -138,6 +138,91 @@ void nvte_grouped_scaled_bias_add(const NVTEGroupedTensor output, const NVTEGrou
                                   const NVTETensor scale, hipStream_t stream);
 
 #ifdef __cplusplus
-}
+}  /* extern "C" */
+
+namespace transformer_engine {
+
+/* ref gemm.h:490-572.  Owns an NVTEMatmulConfig. */
+class MatmulConfigWrapper {
+ public:
+  MatmulConfigWrapper() : config_{nvte_create_matmul_config()} {}
+  MatmulConfigWrapper(const MatmulConfigWrapper &) = delete;
+  MatmulConfigWrapper &operator=(const MatmulConfigWrapper &) = delete;
+  MatmulConfigWrapper(MatmulConfigWrapper &&other) noexcept : config_{other.config_} { other.config_ = nullptr; }
+  MatmulConfigWrapper &operator=(MatmulConfigWrapper &&other) noexcept {
+    if (this != &other) {
+      reset();
+      config_ = other.config_;
+      other.config_ = nullptr;
+    }
+    return *this;
+  }
+  ~MatmulConfigWrapper() { reset(); }
+  operator NVTEMatmulConfig() const noexcept { return config_; }
+
+  void set_bias_tensor(NVTETensor t) { put(kNVTEMatmulConfigBiasTensor, &t, sizeof(t)); }
+  void set_dbias_tensor(NVTETensor t) { put(kNVTEMatmulConfigDBiasTensor, &t, sizeof(t)); }
+  void set_with_gelu_epilogue(bool v) { put_u8(kNVTEMatmulConfigWithGELUEpilogue, v); }
+  void set_with_dgelu_epilogue(bool v) { put_u8(kNVTEMatmulConfigWithDGELUEpilogue, v); }
+  void set_epilogue_aux_tensor(NVTETensor t) { put(kNVTEMatmulConfigEpilogueAuxTensor, &t, sizeof(t)); }
+  void set_use_split_accumulator(bool v) { put_u8(kNVTEMatmulConfigUseSplitAccumulator, v); }
+  void set_sm_count(int v) { put(kNVTEMatmulConfigSMCount, &v, sizeof(v)); }
+
+ private:
+  void put(NVTEMatmulConfigAttribute attr, const void *buf, size_t n) {
+    nvte_set_matmul_config_attribute(config_, attr, buf, n);
+  }
+  void put_u8(NVTEMatmulConfigAttribute attr, bool flag) {
+    const uint8_t v = flag ? 1 : 0;
+    put(attr, &v, sizeof(v));
+  }
+  void reset() noexcept {
+    if (config_ != nullptr) nvte_destroy_matmul_config(config_);
+    config_ = nullptr;
+  }
+  NVTEMatmulConfig config_ = nullptr;
+};
+
+/* ref gemm.h:574-640.  Owns an NVTEGroupedMatmulConfig. */
+class GroupedMatmulConfigWrapper {
+ public:
+  GroupedMatmulConfigWrapper() : config_{nvte_create_grouped_matmul_config()} {}
+  GroupedMatmulConfigWrapper(const GroupedMatmulConfigWrapper &) = delete;
+  GroupedMatmulConfigWrapper &operator=(const GroupedMatmulConfigWrapper &) = delete;
+  GroupedMatmulConfigWrapper(GroupedMatmulConfigWrapper &&other) noexcept : config_{other.config_} {
+    other.config_ = nullptr;
+  }
+  GroupedMatmulConfigWrapper &operator=(GroupedMatmulConfigWrapper &&other) noexcept {
+    if (this != &other) {
+      reset();
+      config_ = other.config_;
+      other.config_ = nullptr;
+    }
+    return *this;
+  }
+  ~GroupedMatmulConfigWrapper() { reset(); }
+  operator NVTEGroupedMatmulConfig() const noexcept { return config_; }
+
+  void set_avg_m(int64_t v) { put(kNVTEGroupedMatmulConfigAvgM, &v, sizeof(v)); }
+  void set_avg_n(int64_t v) { put(kNVTEGroupedMatmulConfigAvgN, &v, sizeof(v)); }
+  void set_avg_k(int64_t v) { put(kNVTEGroupedMatmulConfigAvgK, &v, sizeof(v)); }
+  void set_sm_count(int v) { put(kNVTEGroupedMatmulConfigSMCount, &v, sizeof(v)); }
+  void set_use_split_accumulator(bool flag) {
+    const uint8_t v = flag ? 1 : 0;
+    put(kNVTEGroupedMatmulConfigUseSplitAccumulator, &v, sizeof(v));
+  }
+
+ private:
+  void put(NVTEGroupedMatmulConfigAttribute attr, const void *buf, size_t n) {
+    nvte_set_grouped_matmul_config_attribute(config_, attr, buf, n);
+  }
+  void reset() noexcept {
+    if (config_ != nullptr) nvte_destroy_grouped_matmul_config(config_);
+    config_ = nullptr;
+  }
+  NVTEGroupedMatmulConfig config_ = nullptr;
+};
+
+}  // namespace transformer_engine
 #endif
 #endif

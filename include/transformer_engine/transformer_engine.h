@@ -203,6 +203,10 @@ enum NVTEGroupedTensorParam {
 
 #ifdef __cplusplus
 } /* extern "C" */
+
+/* C++ callers also get namespace transformer_engine (DType, TensorWrapper, QuantizationConfigWrapper, ...),
+ * ref transformer_engine.h:670-1515: a header-only layer over the entry points above. */
+#include "cxx_wrappers.h"
 #endif
 
 #endif /* TE_AMD_TRANSFORMER_ENGINE_H_ */

@@ -42,8 +42,10 @@ def test_every_declared_symbol_is_exported():
     missing = [n for n in declared
                if n not in exported and n != "nvte_delayed_scaling_recipe_amax_and_scale_update_after_reduction"]
     assert not missing, f"declared but not exported: {missing}"
-    # nothing but the nvte_* surface leaks out of the shared object
-    leaked = [s for s in exported if not s.startswith("nvte_") and "nvte_delayed_scaling" not in s]
+    # nothing but the nvte_* surface and the transformer_engine:: C++ helpers of runtime.h (the symbols the
+    # reference's version script lists, ref common/libtransformer_engine.version:5-17) leaves the shared object
+    leaked = [s for s in exported if not s.startswith("nvte_") and "nvte_delayed_scaling" not in s
+              and not s.startswith("_ZN18transformer_engine")]
     assert not leaked, leaked[:5]
 
 
