@@ -33,6 +33,9 @@ import torch  # noqa: E402
 
 PEAK_FP8_TFLOPS = 5000.0   # dense FP8 MFMA, MI355X_MICROARCH.md "Peak FP8 MFMA ~5 PF dense"
 PEAK_HBM_GBPS = 8000.0     # HBM3E spec, MI355X_MICROARCH.md
+# newest first: the PMC passes (profiles/collect.sh) of the kernels this tree ships; each file records the
+# commit and date it was taken at under "_meta"
+TRAFFIC_FILES = ("round2_traffic.json", "round1_traffic.json")
 
 
 def parse():
@@ -45,6 +48,9 @@ def parse():
     ap.add_argument("--out-features", type=int, default=14336)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--parallelism", choices=["dp", "tp_sp"], default="dp")
+    ap.add_argument("--tp-layer", choices=["column", "row", "ln_column"], default="column",
+                    help="tp_sp: column-parallel Linear (default), row-parallel Linear, or column-parallel LayerNormLinear (configs[3])")
+    ap.add_argument("--tp-chunks", type=int, default=2, help="tp_sp: pieces the AG+GEMM / GEMM+RS pipelines are cut into")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -56,11 +62,14 @@ def load_traffic():
     """Fabric-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
     gfx950 + WRITE_SIZE, see profiles/README.md).  Counters cannot be read from inside this
     process, so the figures come from the separate profiled run of the same kernels and shapes."""
-    path = os.path.join(ROOT, "profiles", "round1_traffic.json")
-    if not os.path.exists(path):
-        return {}
-    with open(path) as fh:
-        return json.load(fh)
+    for name in TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                table = json.load(fh)
+            table["_file"] = "profiles/" + name
+            return table
+    return {}
 
 
 def traffic_of(table, role):
@@ -199,15 +208,28 @@ def main():
         global_tokens = M * world
     else:
         from transformer_engine_amd import distributed as D
-        mod = D.ColumnParallelLinearSP(K, N, world, rank, recipe, device=dev)
-        x_local = torch.randn(M, K, device=dev, dtype=torch.bfloat16)        # this rank's tokens
-        dy = (torch.randn(M * world, N // world, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
+
+        def make_tp(overlap):
+            kw = dict(device=dev, overlap=overlap, chunks=args.tp_chunks)
+            if args.tp_layer == "row":
+                return D.RowParallelLinearSP(K, N, world, rank, recipe, **kw)
+            if args.tp_layer == "ln_column":
+                return D.ColumnParallelLayerNormLinearSP(K, N, world, rank, recipe, **kw)
+            return D.ColumnParallelLinearSP(K, N, world, rank, recipe, **kw)
+
+        mod = make_tp(True)
+        if args.tp_layer == "row":      # all tokens x local features in, local tokens x N out
+            x_local = torch.randn(M * world, K // world, device=dev, dtype=torch.bfloat16)
+            dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
+        else:                           # local tokens x K in, all tokens x local output columns out
+            x_local = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            dy = (torch.randn(M * world, N // world, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
 
         def step(first=False):
             return mod.step(x_local, dy, is_first_microbatch=first)
 
         flops_per_step = 6.0 * (M * world) * N * K      # whole job
-        parallelism = f"tp{world}+sp"
+        parallelism = f"tp{world}+sp ({args.tp_layer}-parallel)"
         global_tokens = M * world
 
     # warm the scales (>= 2 steps so delayed scaling values are in range), cache the FP8 weight
@@ -309,6 +331,50 @@ def main():
         "tflops_per_gpu": tflops / world,
     }
 
+    if world > 1 and args.parallelism == "tp_sp":
+        # ---- exposed communication: the same step (a) with the pipelines switched off (one blocking
+        # collective, then the whole GEMM) and (b) the step's collectives alone, same sizes, back to back.
+        # comm_ms = (b); overlap_frac = the share of (b) the overlapped schedule hides = ((a) - step) / (b).
+        def timed(fn, iters):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / iters * 1e3],
+                             device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        serial = make_tp(False)
+        serial.weight = mod.weight
+        serial.step(x_local, dy, is_first_microbatch=True)
+        it = max(3, args.steps // 4)
+        serial_ms = timed(lambda: serial.step(x_local, dy, is_first_microbatch=False), it)
+        if args.tp_layer == "row":
+            rs_src = torch.empty(M * world, N, device=dev, dtype=torch.bfloat16)      # Y partial sums
+            ag_src = torch.empty(M, N, device=dev, dtype=torch.uint8)                 # dY FP8 bytes
+        else:
+            rs_src = torch.empty(M * world, K, device=dev, dtype=torch.bfloat16)      # dgrad partial sums
+            ag_src = torch.empty(M, K, device=dev, dtype=torch.uint8)                 # X FP8 bytes
+        amax = torch.zeros(3, device=dev)
+
+        def comm_only():
+            D.all_gather_rows(ag_src, None)
+            D.all_reduce_max_(amax, None)
+            D.reduce_scatter_along_first_dim(rs_src, None)
+            D.all_reduce_max_(amax[:2], None)
+
+        comm_ms = timed(comm_only, it)
+        result["comm_ms"] = comm_ms
+        result["serial_ms_per_step"] = serial_ms
+        result["overlap_frac"] = max(0.0, min(1.0, (serial_ms - ms_per_step) / comm_ms)) if comm_ms > 0 else None
+        result["comm_bytes_per_rank"] = {"all_gather_fp8": ag_src.numel() * (world - 1),
+                                         "reduce_scatter_bf16": rs_src.numel() * 2 * (world - 1) // world}
+        result["config"]["tp_chunks"] = args.tp_chunks
+
     if rank == 0 and world == 1:
         # ---- per-kernel measurements (HIP events on the launch stream) -------------------------
         from transformer_engine_amd import general_gemm
@@ -388,10 +454,27 @@ def main():
                                              "traffic": traffic_of(traffic, "cast_transpose_dy") if default_shape else None,
                                              "algorithmic_bytes": ct_bytes,
                                              "kernel": "cast_transpose_tile_kernel on dY [8192,14336] bf16->e5m2, 4 B/element"}
+        meta = traffic.get("_meta", {})
+        result["roofline"]["traffic_source"] = {
+            "file": traffic.get("_file"), "commit": meta.get("commit"), "date": meta.get("date"),
+            "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of profiles/pmc_target.py (same kernels, same "
+                   "shapes), not read live: counters cannot be collected from inside this process"}
         result["roofline"]["launch_ms"] = {k: step_ms[k] for k in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")}
         result["roofline"]["timing"] = "HIP events around each launch inside args.steps eager steps of the timed workload"
         result["roofline_cast_transpose"]["launch_ms"] = step_ms["cast_transpose_dy"]
+        # headline both ways: `value` amortises the weight quantize as te.Linear does with
+        # is_first_microbatch=False; the other figure charges one full weight cast_transpose to every step
+        result["value_incl_weight_quantize"] = flops_per_step / ((ms_per_step + t_ct_w) * 1e-3) / 1e12
+        hot_ms = sum(step_ms.values())
         result["extra"] = {
+            "step_breakdown": {
+                "ms_per_step": ms_per_step, "hot_kernels_ms": hot_ms,
+                "gemm_ms": step_ms["gemm_fprop"] + step_ms["gemm_dgrad"] + step_ms["gemm_wgrad"],
+                "cast_transpose_ms": step_ms["cast_transpose_x"] + step_ms["cast_transpose_dy"],
+                "recipe_kernels_and_launch_gaps_ms": ms_per_step - hot_ms,
+                "recipe_kernels_and_launch_gaps_share": (ms_per_step - hot_ms) / ms_per_step,
+                "note": "hot kernels timed in eager instrumented steps, ms_per_step from the hipGraph replay: the "
+                        "remainder is the two recipe-update kernels, two amax memsets and the graph's inter-kernel gaps"},
             "in_step_ms": step_ms,
             "isolated_note": "gemm_ms / cast_transpose_ms below: the same kernel launched back to back on resident "
                              "operands (upper bound: inputs partly stay in the Infinity Cache)",

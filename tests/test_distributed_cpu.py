@@ -80,6 +80,47 @@ def _case_gemm_and_reduce_scatter(rank, world):
     assert torch.allclose(mine, expect[rank * 4:(rank + 1) * 4], atol=1e-5)
 
 
+def _case_kchunked_gather_and_gemm(rank, world):
+    """AG + GEMM cut along the contraction dim: every chunk is one full all-gather, the chunk GEMMs
+    accumulate, the gathered chunks side by side are the plain all-gather."""
+    from transformer_engine_amd import distributed as D
+    g = torch.Generator().manual_seed(17)
+    K = 640
+    full = torch.randint(0, 255, (world * 6, K), generator=g, dtype=torch.uint8)
+    w = torch.randn(5, K, generator=g)
+    local = full[rank * 6:(rank + 1) * 6].clone()
+    y = torch.zeros(world * 6, 5)
+    seen = []
+
+    def gemm(buf, i, k0, k1):
+        assert buf.shape == (world * 6, k1 - k0)
+        seen.append((i, k0, k1))
+        y.add_(buf.float() @ w[:, k0:k1].t())
+
+    bufs = D.gather_and_gemm_kchunked(local, gemm, None, chunks=3)
+    assert [s[0] for s in seen] == [0, 1, 2] and seen[0][1] == 0 and seen[-1][2] == K
+    assert all(k0 % 128 == 0 for _, k0, _ in seen)
+    assert torch.equal(torch.cat(bufs, dim=1), full)          # bit-exact all-gather of bytes
+    assert torch.allclose(y, full.float() @ w.t(), rtol=1e-5, atol=1e-2)
+    assert D.split_points(384, 2) == [(0, 256), (256, 384)] and D.split_points(100, 4) == [(0, 100)]
+
+
+def _case_nchunked_gemm_and_reduce_scatter(rank, world):
+    from transformer_engine_amd import distributed as D
+    g = torch.Generator().manual_seed(19)
+    N = 384
+    x_all = [torch.randn(world * 4, 7, generator=g) for _ in range(world)]
+    w_all = [torch.randn(N, 7, generator=g) for _ in range(world)]
+    expect = sum(x_all[r] @ w_all[r].t() for r in range(world))
+
+    def gemm(c0, c1):
+        return x_all[rank] @ w_all[rank][c0:c1].t()
+
+    mine = D.gemm_and_reduce_scatter_nchunked(N, gemm, None, chunks=2)
+    assert mine.shape == (4, N)
+    assert torch.allclose(mine, expect[rank * 4:(rank + 1) * 4], atol=1e-4)
+
+
 def _case_amax_reduction(rank, world):
     """delayed-scaling amax buffer: ONE MAX all-reduce of the packed buffer (ref quantization.py:666-674)."""
     buf = torch.tensor([1.0 + rank, 5.0 - rank, 0.0])
@@ -93,6 +134,14 @@ def test_gather_and_gemm_overlap_schedule():
 
 def test_gemm_and_reduce_scatter_overlap_schedule():
     _run("_case_gemm_and_reduce_scatter")
+
+
+def test_kchunked_gather_and_gemm_schedule():
+    _run("_case_kchunked_gather_and_gemm")
+
+
+def test_nchunked_gemm_and_reduce_scatter_schedule():
+    _run("_case_nchunked_gemm_and_reduce_scatter")
 
 
 def test_amax_max_reduction():

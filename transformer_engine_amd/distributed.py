@@ -5,28 +5,38 @@ Mirrors the reference's ``transformer_engine/pytorch/distributed.py``:
 (:1524-1662), ``reduce_scatter_along_first_dim`` (:928-955), ``allreduce`` (:2051-2065), and
 REPLACES ``common/comm_gemm_overlap`` (userbuffers: IPC buffers + hand-written ring kernels,
 ``comm_gemm_overlap.cpp:444-1390``) with plain RCCL collectives issued on PyTorch's
-communication stream and consumed chunk by chunk by GEMMs on the compute stream:
+communication stream and consumed chunk by chunk by GEMMs on the compute stream.
 
-  * AG + GEMM (``split_overlap_ag``, :1044):  one ``broadcast`` per source rank instead of a
-    ring - the 8-GPU xGMI node is fully connected, so every shard goes straight to its 7
-    readers; GEMM on shard r starts when broadcast r has landed (stream-ordered, no host
-    sync), while later shards are still in flight.
-  * GEMM + RS (``split_overlap_rs``, :611): the output is produced in ``tp`` row blocks; block c
-    is reduced to rank c (``reduce``) while block c+1 is being multiplied.
+How the overlap is cut (round 2; the per-source-rank ``broadcast`` pipeline of round 1 is kept only as
+``gather_and_gemm_by_shard``):
+
+  * AG + GEMM (``split_overlap_ag``, :1044).  The CONTRACTION dimension is cut, not the rows: chunk i
+    is ``all_gather_into_tensor`` of the local FP8 bytes ``[m, K_i]`` - ONE full-width collective that
+    uses all seven xGMI links of every GPU at once (a per-source broadcast or a ring is bound by one
+    ≈153 GB/s link) - and lands as ``[tp*m, K_i]`` in natural token order.  GEMM i multiplies it with
+    the matching K slice of the (cached, pre-sliced) FP8 weight and ACCUMULATES into the output, so it
+    is a full-size persistent launch (all 256 CUs busy) that waits for chunk i only.  The transposes
+    of the gathered chunks are the row blocks of X^T that wgrad needs: nothing is re-gathered.
+  * GEMM + RS (``split_overlap_rs``, :611).  The OUTPUT columns are cut: GEMM j produces
+    ``[M, N_j]`` with a row slice of the FP8 weight (contiguous, no copy) and its
+    ``reduce_scatter_tensor`` runs while GEMM j+1 computes; the pieces are concatenated.
   * bulk overlap (:444): an independent collective (dgrad reduce-scatter) runs beside a whole
     GEMM (wgrad).
 
-The byte-moving helpers take plain tensors and a ``gemm`` callback so that the chunk
-bookkeeping is testable on CPU with gloo (tests/test_distributed_cpu.py).
+Every collective is issued with ``async_op=True`` and joined with ``work.wait()``: on RCCL that
+stream-orders the consumer behind the collective without a host sync.  The byte-moving helpers take
+plain tensors and callbacks so that the chunk bookkeeping is testable on CPU with gloo
+(tests/test_distributed_cpu.py).  No multi-GPU hardware run exists yet (the build box has one GPU);
+the 2-rank tests use gloo with both ranks on one device.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .recipe import DelayedScaling, reduce_and_update_fp8_tensors
+from .recipe import DelayedScaling, Float8CurrentScaling, MXFP8BlockScaling, reduce_and_update_fp8_tensors
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor,
                      MXFP8Quantizer, MXFP8Tensor)
 
@@ -37,14 +47,35 @@ def get_distributed_world_size(group=None) -> int:
     return dist.get_world_size(group=group)
 
 
+def _is_gloo(group) -> bool:
+    return dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
 # ---------------------------------------------------------------------------------------
 # plain-tensor collectives
 # ---------------------------------------------------------------------------------------
+class _Done:
+    """Stand-in for a finished collective (gloo rehearsals run synchronously on the host)."""
+
+    def wait(self):
+        return True
+
+
 def all_gather_rows(local: torch.Tensor, group=None, async_op: bool = False):
     """[m, ...] per rank -> [tp*m, ...] (rank-major).  One all_gather_into_tensor."""
     tp = get_distributed_world_size(group)
     if tp == 1:
         return local, None
+    if _is_gloo(group) and local.is_cuda:
+        # rehearsal path (two ranks on one GPU): staged through the host and finished on return; gloo's
+        # own device staging was seen to stall there
+        src = local.detach().contiguous().view(torch.uint8).cpu() if local.dtype == torch.bfloat16 else local.detach().contiguous().cpu()
+        gathered = torch.empty((src.shape[0] * tp,) + tuple(src.shape[1:]), dtype=src.dtype)
+        dist.all_gather_into_tensor(gathered, src, group=group)
+        out = gathered.to(local.device)
+        if local.dtype == torch.bfloat16:
+            out = out.view(torch.bfloat16)
+        return out, (_Done() if async_op else None)
     out = torch.empty((local.shape[0] * tp,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     handle = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
     return out, handle
@@ -56,7 +87,7 @@ def reduce_scatter_along_first_dim(x: torch.Tensor, group=None, async_op: bool =
     if tp == 1:
         return x, None
     assert x.shape[0] % tp == 0, "first dim must divide by the tensor-parallel size"
-    if dist.get_backend(group) == "gloo":
+    if _is_gloo(group):
         # gloo (CPU rehearsals / single-GPU tests) has no reduce_scatter: all-reduce and slice
         # (on the host: gloo's own CUDA staging was seen to stall when two ranks share one GPU)
         full = x.detach().to("cpu", copy=True).contiguous()
@@ -65,7 +96,7 @@ def reduce_scatter_along_first_dim(x: torch.Tensor, group=None, async_op: bool =
         dist.all_reduce(full, group=group)
         m = x.shape[0] // tp
         r = dist.get_rank(group)
-        return full[r * m:(r + 1) * m].to(device=x.device, dtype=x.dtype).contiguous(), None
+        return full[r * m:(r + 1) * m].to(device=x.device, dtype=x.dtype).contiguous(), (_Done() if async_op else None)
     out = torch.empty((x.shape[0] // tp,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     handle = dist.reduce_scatter_tensor(out, x.contiguous(), group=group, async_op=async_op)
     return out, handle
@@ -79,11 +110,82 @@ def allreduce(x: torch.Tensor, group=None, async_op: bool = False):
     return x, handle
 
 
+def all_reduce_max_(t: torch.Tensor, group=None) -> None:
+    """In-place MAX all-reduce of an amax buffer (gloo rehearsals reduce on the host)."""
+    if get_distributed_world_size(group) == 1:
+        return
+    if _is_gloo(group) and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+
+
+def split_points(total: int, chunks: int, align: int = 128) -> List[Tuple[int, int]]:
+    """Cut [0, total) into at most `chunks` pieces whose boundaries are multiples of `align`
+    (FP8 GEMM operands need 16-byte rows, MXFP8 whole 32-element blocks, the GEMM K tile is 128)."""
+    units = max(total // align, 1)
+    chunks = max(1, min(chunks, units))
+    base, extra = divmod(units, chunks)
+    pts, start = [], 0
+    for i in range(chunks):
+        n = (base + (1 if i < extra else 0)) * align
+        end = total if i == chunks - 1 else start + n
+        pts.append((start, end))
+        start = end
+    return pts
+
+
+def gather_and_gemm_kchunked(local: torch.Tensor, gemm: Callable[[torch.Tensor, int, int, int], None],
+                             group=None, chunks: int = 2, align: int = 128) -> List[torch.Tensor]:
+    """AG + GEMM overlap, cut along the contraction dimension.
+
+    ``local`` is this rank's ``[m, K]`` byte matrix.  For chunk i = columns [k0, k1) the gathered
+    ``[tp*m, k1-k0]`` buffer (natural row order) is handed to ``gemm(buf, i, k0, k1)`` as soon as ITS
+    all-gather has landed; all collectives are issued up front (they run back to back on the
+    communication stream, each using every link).  Returns the gathered chunks."""
+    tp = get_distributed_world_size(group)
+    m, K = local.shape
+    pts = split_points(K, chunks if tp > 1 else 1, align)
+    bufs, works = [], []
+    for k0, k1 in pts:
+        piece = local if (k0 == 0 and k1 == K) else local[:, k0:k1].contiguous()
+        if tp == 1:
+            bufs.append(piece); works.append(None)
+            continue
+        out, work = all_gather_rows(piece, group, async_op=True)
+        works.append(work)
+        bufs.append(out)
+    for i, (k0, k1) in enumerate(pts):
+        if works[i] is not None:
+            works[i].wait()              # stream-orders GEMM i behind all-gather i only
+        gemm(bufs[i], i, k0, k1)
+    return bufs
+
+
+def gemm_and_reduce_scatter_nchunked(n_cols: int, gemm: Callable[[int, int], torch.Tensor], group=None,
+                                     chunks: int = 2, align: int = 128) -> torch.Tensor:
+    """GEMM + RS overlap, cut along the output columns.  ``gemm(c0, c1)`` returns the partial sums
+    ``[M, c1-c0]`` (contiguous); its reduce-scatter runs while the next piece is computed.  Returns
+    this rank's ``[M/tp, n_cols]``."""
+    tp = get_distributed_world_size(group)
+    pts = split_points(n_cols, chunks if tp > 1 else 1, align)
+    outs, works = [], []
+    for c0, c1 in pts:
+        part = gemm(c0, c1)
+        o, w = reduce_scatter_along_first_dim(part, group, async_op=True)
+        outs.append(o); works.append(w)
+    for w in works:
+        if w is not None:
+            w.wait()
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+
+
 def gather_and_gemm_by_shard(local: torch.Tensor, gemm: Callable[[torch.Tensor, int], None],
                              group=None, gathered: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """AG + GEMM overlap.  ``gemm(shard, r)`` is called once per source rank r with that rank's
-    rows (a view of the gathered buffer, rows [r*m, (r+1)*m)); the call for the local shard comes
-    first and needs no communication.  Returns the gathered buffer."""
+    """Round-1 schedule, kept for comparison: one ``broadcast`` per source rank, GEMM on shard r behind
+    broadcast r.  tp collectives that each use one link; superseded by gather_and_gemm_kchunked."""
     tp = get_distributed_world_size(group)
     rank = dist.get_rank(group) if tp > 1 else 0
     m = local.shape[0]
@@ -109,9 +211,7 @@ def gather_and_gemm_by_shard(local: torch.Tensor, gemm: Callable[[torch.Tensor, 
 
 def gemm_and_reduce_scatter_by_block(total_rows: int, gemm: Callable[[int, int], torch.Tensor],
                                      group=None) -> torch.Tensor:
-    """GEMM + RS overlap.  ``gemm(row0, rows)`` returns the partial-sum block for output rows
-    [row0, row0+rows); block c is sum-reduced to rank c while block c+1 is computed.  Returns this
-    rank's reduced block [total_rows/tp, ...]."""
+    """Round-1 schedule, kept for comparison: GEMM per destination row block + ``reduce`` to that rank."""
     tp = get_distributed_world_size(group)
     rank = dist.get_rank(group) if tp > 1 else 0
     assert total_rows % tp == 0
@@ -133,9 +233,9 @@ def gemm_and_reduce_scatter_by_block(total_rows: int, gemm: Callable[[int, int],
 # quantized gathers
 # ---------------------------------------------------------------------------------------
 def _all_gather_fp8(q: Float8Tensor, group=None, need_transpose: bool = False) -> Float8Tensor:
-    """All-gather the ROWWISE FP8 bytes; scale_inv is identical on every rank by construction
-    (delayed scaling: the amax history is max-reduced over the group; current scaling: the amax
-    is all-reduced before the scale is computed) - ref pytorch/distributed.py:1056-1075."""
+    """All-gather the ROWWISE FP8 bytes; scale_inv must be identical on every rank (delayed scaling: the
+    amax history is max-reduced over the group; current scaling: the quantizer all-reduces the amax
+    before the scale is computed - configure_amax_reduction below) - ref pytorch/distributed.py:1056-1075."""
     data, _ = all_gather_rows(q._data.view(-1, q.shape[-1]), group)
     out = Float8Tensor(shape=(data.shape[0], q.shape[-1]), dtype=q.dtype, data=data,
                        fp8_scale_inv=q._scale_inv, fp8_dtype=q._fp8_dtype, quantizer=q._quantizer)
@@ -145,30 +245,49 @@ def _all_gather_fp8(q: Float8Tensor, group=None, need_transpose: bool = False) -
 
 
 def _all_gather_mxfp8(q: MXFP8Tensor, group=None) -> MXFP8Tensor:
-    """Gather rowwise data and rowwise e8m0 scales (compact layout, padding rows stripped and
-    re-added) - ref pytorch/distributed.py:1614-1659."""
+    """Gather rowwise data + rowwise e8m0 scales and - when present - the TRANSPOSED columnwise pair
+    (amd_ext.h layout: payload [K, m], scales [pad128(K), pad4(m/32)]), compact scales, padding stripped
+    and re-added (ref pytorch/distributed.py:1614-1659 gathers the reference's columnwise pair the same
+    way).  A rank's rows are a whole number of 32-row blocks, so the gathered transposed payload is the
+    per-rank payloads side by side: [K, tp*m]."""
     assert not q._with_gemm_swizzled_scales, "all-gather needs compact (unswizzled) scales"
     tp = get_distributed_world_size(group)
-    rows = q.numel() // q.shape[-1]
-    data, _ = all_gather_rows(q._rowwise_data.view(rows, q.shape[-1]), group)
-    sc_local = q._rowwise_scale_inv[:rows].contiguous()
-    sc, _ = all_gather_rows(sc_local, group)
-    pad = (-sc.shape[0]) % 128
-    if pad:
-        sc = torch.cat([sc, torch.zeros(pad, sc.shape[1], dtype=sc.dtype, device=sc.device)])
-    return MXFP8Tensor(shape=(rows * tp, q.shape[-1]), dtype=q.dtype, rowwise_data=data,
-                       rowwise_scale_inv=sc, columnwise_data=None, columnwise_scale_inv=None,
-                       fp8_dtype=q._fp8_dtype, quantizer=q._quantizer)
+    K = q.shape[-1]
+    rows = q.numel() // K
+    rd = rs = cd = cs = None
+    if q._rowwise_data is not None:
+        rd, _ = all_gather_rows(q._rowwise_data.view(rows, K), group)
+        rs, _ = all_gather_rows(q._rowwise_scale_inv[:rows].contiguous(), group)
+        pad = (-rs.shape[0]) % 128
+        if pad:
+            rs = torch.cat([rs, torch.zeros(pad, rs.shape[1], dtype=rs.dtype, device=rs.device)])
+    if q._columnwise_data is not None:
+        if not q._columnwise_transposed:
+            raise NotImplementedError("all-gather of the reference-layout columnwise MXFP8 payload is not "
+                                      "implemented: quantize with columnwise_transposed=True")
+        if rows % 32 != 0:
+            raise ValueError("MXFP8 sequence-parallel shards need a multiple of 32 rows per rank")
+        nb = rows // 32
+        cdl, _ = all_gather_rows(q._columnwise_data.view(1, K, rows), group)           # [tp, K, m]
+        cd = cdl.permute(1, 0, 2).reshape(K, tp * rows).contiguous()
+        csl, _ = all_gather_rows(q._columnwise_scale_inv[:K, :nb].contiguous().view(1, K, nb), group)
+        cs_c = csl.permute(1, 0, 2).reshape(K, tp * nb)
+        cs = torch.zeros((K + 127) // 128 * 128, (tp * nb + 3) // 4 * 4, dtype=cs_c.dtype, device=cs_c.device)
+        cs[:K, :tp * nb] = cs_c
+    return MXFP8Tensor(shape=(rows * tp, K), dtype=q.dtype, rowwise_data=rd, rowwise_scale_inv=rs,
+                       columnwise_data=cd, columnwise_scale_inv=cs, fp8_dtype=q._fp8_dtype,
+                       quantizer=q._quantizer, columnwise_transposed=cd is not None)
 
 
 def gather_along_first_dim(inp, group=None, quantizer=None, need_transpose: bool = False):
-    """ref pytorch/distributed.py:1665: quantize locally (rowwise only: a gathered transpose is
-    not the transpose of the gather, linear.py:361-363), then all-gather bytes."""
+    """ref pytorch/distributed.py:1665: quantize locally (rowwise only for per-tensor FP8: a gathered
+    transpose is not the transpose of the gather, linear.py:361-363), then all-gather bytes."""
     if isinstance(inp, torch.Tensor):
         if quantizer is None:
             out, _ = all_gather_rows(inp, group)
             return out
-        quantizer.set_usage(rowwise=True, columnwise=False)
+        if not isinstance(quantizer, MXFP8Quantizer):
+            quantizer.set_usage(rowwise=True, columnwise=False)
         inp = quantizer(inp)
     if isinstance(inp, Float8Tensor):
         return _all_gather_fp8(inp, group, need_transpose)
@@ -177,18 +296,28 @@ def gather_along_first_dim(inp, group=None, quantizer=None, need_transpose: bool
     raise TypeError(type(inp))
 
 
+def configure_amax_reduction(quantizer, group) -> None:
+    """A tensor that is sharded over `group` and gathered in FP8 must be quantized with ONE scale on
+    every rank.  Current scaling: the amax is MAX-all-reduced over the group before the scale is
+    computed (ref module/linear.py:319-322, csrc/quantizer.cpp:994-999).  Delayed scaling gets the same
+    from the recipe step's packed amax all-reduce; MXFP8 scales are per block and need nothing."""
+    if isinstance(quantizer, Float8CurrentScalingQuantizer) and get_distributed_world_size(group) > 1:
+        quantizer.with_amax_reduction = True
+        quantizer.amax_reduction_group = group
+
+
 # ---------------------------------------------------------------------------------------
 # column-parallel + sequence-parallel Linear (the C4 pattern, ref module/linear.py:314-549,
 # :760-1261 with sequence_parallel=True, parallel_mode="column")
 # ---------------------------------------------------------------------------------------
 class ColumnParallelLinearSP:
     """Weight shard [N/tp, K]; activations sharded on tokens.  forward: FP8 all-gather of X
-    overlapped with the per-shard GEMMs; backward: dgrad partial sums reduce-scattered to the
+    overlapped with the K-chunked GEMMs; backward: dgrad partial sums reduce-scattered to the
     token shard while wgrad runs; amax all-reduce (MAX) once per fwd and once per bwd."""
 
     def __init__(self, in_features: int, out_features: int, tp: int, rank: int, recipe=None,
-                 device=None, group=None, params_dtype=torch.bfloat16, overlap: bool = True):
-        from .linear import LinearFP8State
+                 device=None, group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2):
+        from .linear import FWD_INPUT, LinearFP8State
         assert out_features % tp == 0
         self.K, self.N_local, self.tp, self.rank, self.group = in_features, out_features // tp, tp, rank, group
         self.device = device or torch.device("cuda")
@@ -196,36 +325,72 @@ class ColumnParallelLinearSP:
         self.weight = (torch.randn(self.N_local, in_features, generator=g) * 0.02).to(params_dtype).to(self.device)
         self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device)
         self.overlap = overlap
+        self.chunks = chunks
         self.out_dtype = params_dtype
+        # the input is sharded on tokens and gathered in FP8: one scale over the whole group
+        configure_amax_reduction(self.state.fwd_q[FWD_INPUT], group)
+        self._w_chunks = None      # K slices of the cached FP8 weight (bytes), for the chunked forward
 
-    def forward(self, x_local: torch.Tensor, is_first_microbatch=None):
-        from .gemm import general_gemm
-        from .linear import FWD_INPUT, FWD_WEIGHT
+    # -- pieces shared with the LayerNorm variant -----------------------------------------
+    def _cached_weight(self, is_first_microbatch):
+        from .linear import FWD_WEIGHT
         st = self.state
-        qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
+        qw = st.fwd_q[FWD_WEIGHT]
         if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
             qw.set_usage(rowwise=True, columnwise=True)
             st.weight_cache = qw(self.weight)
-        w8 = st.weight_cache
-        qi.set_usage(rowwise=True, columnwise=False)
-        x8_local = qi(x_local)
-        m, tp = x_local.shape[0], self.tp
+            self._w_chunks = None
+        return st.weight_cache
+
+    def _weight_k_chunks(self, w8: Float8Tensor, pts):
+        if self._w_chunks is None or self._w_chunks[0] != pts:
+            views = [Float8Tensor(shape=(self.N_local, k1 - k0), dtype=w8.dtype,
+                                  data=w8._data[:, k0:k1].contiguous(), fp8_scale_inv=w8._scale_inv,
+                                  fp8_dtype=w8._fp8_dtype) for k0, k1 in pts]
+            self._w_chunks = (pts, views)
+        return self._w_chunks[1]
+
+    def _quantize_input(self, x_local):
+        from .linear import FWD_INPUT
+        qi = self.state.fwd_q[FWD_INPUT]
+        if isinstance(qi, MXFP8Quantizer):
+            qi.set_usage(rowwise=True, columnwise=True)      # the transposed columnwise pair is gathered too
+        else:
+            qi.set_usage(rowwise=True, columnwise=False)
+        return qi(x_local)
+
+    def _gather_and_gemm(self, x8_local, w8, m):
+        """Returns (y, x8 for backward)."""
+        from .gemm import general_gemm
+        tp = self.tp
         y = torch.empty(m * tp, self.N_local, dtype=self.out_dtype, device=self.device)
         if self.overlap and tp > 1 and isinstance(x8_local, Float8Tensor):
-            def shard_gemm(shard_bytes, r):
-                xs = Float8Tensor(shape=(m, self.K), dtype=x_local.dtype, data=shard_bytes,
+            pts = tuple(split_points(self.K, self.chunks))
+            w_chunks = self._weight_k_chunks(w8, pts)
+
+            def chunk_gemm(buf, i, k0, k1):
+                xs = Float8Tensor(shape=(m * tp, k1 - k0), dtype=self.out_dtype, data=buf,
                                   fp8_scale_inv=x8_local._scale_inv, fp8_dtype=x8_local._fp8_dtype)
-                general_gemm(w8, xs, layout="TN", out=y[r * m:(r + 1) * m])
-            gathered = gather_and_gemm_by_shard(x8_local._data, shard_gemm, self.group)
-            x8 = Float8Tensor(shape=(m * tp, self.K), dtype=x_local.dtype, data=gathered,
-                              fp8_scale_inv=x8_local._scale_inv, fp8_dtype=x8_local._fp8_dtype)
+                general_gemm(w_chunks[i], xs, layout="TN", out=y, accumulate=i > 0)
+
+            bufs = gather_and_gemm_kchunked(x8_local._data.view(m, self.K), chunk_gemm, self.group, self.chunks)
+            # backward only needs X^T: the transposes of the gathered chunks are its row blocks
+            x8 = _GatheredChunks(bufs, pts, x8_local)
         else:
             x8 = gather_along_first_dim(x8_local, self.group)
             general_gemm(w8, x8, layout="TN", out=y)
+        return y, x8
+
+    def forward(self, x_local: torch.Tensor, is_first_microbatch=None):
+        st = self.state
+        w8 = self._cached_weight(is_first_microbatch)
+        x8_local = self._quantize_input(x_local)
+        y, x8 = self._gather_and_gemm(x8_local, w8, x_local.shape[0])
         st.update_fwd(self.group)
         return y, (x8, w8)
 
-    def backward(self, dy: torch.Tensor, saved):
+    def _backward_gemms(self, dy: torch.Tensor, saved):
+        """Returns (dx_local [m, K] after reduce-scatter, dw)."""
         from .gemm import general_gemm
         from .linear import BWD_GRAD_OUTPUT
         x8, w8 = saved
@@ -237,15 +402,192 @@ class ColumnParallelLinearSP:
         dx_partial, *_ = general_gemm(w8, dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
         dx_local, handle = reduce_scatter_along_first_dim(dx_partial, self.group, async_op=True)
         # wgrad needs X^T of the GATHERED input: rebuilt locally (ref distributed.py:1067-1075)
-        if isinstance(x8, Float8Tensor) and (x8._transpose is None or x8._transpose_invalid):
+        if isinstance(x8, _GatheredChunks):
+            x8 = x8.as_transposed_tensor()
+        elif isinstance(x8, Float8Tensor) and (x8._transpose is None or x8._transpose_invalid):
             x8._create_transpose()
         dw, *_ = general_gemm(x8, dy8, out_dtype=self.out_dtype, layout="NT", grad=True)
         if handle is not None:
             handle.wait()
-        st.update_bwd(self.group)
+        return dx_local, dw
+
+    def backward(self, dy: torch.Tensor, saved):
+        dx_local, dw = self._backward_gemms(dy, saved)
+        self.state.update_bwd(self.group)
         return dx_local, dw
 
     def step(self, x_local, dy, is_first_microbatch=None):
         y, saved = self.forward(x_local, is_first_microbatch)
         dx, dw = self.backward(dy, saved)
+        return y, dx, dw
+
+
+class _GatheredChunks:
+    """The K-chunked all-gather result kept for backward: wgrad reads X^T [K, M], whose row block
+    [k0, k1) is the byte transpose of gathered chunk i."""
+
+    def __init__(self, bufs: Sequence[torch.Tensor], pts, like: Float8Tensor):
+        self.bufs, self.pts, self.like = list(bufs), list(pts), like
+
+    def rowwise_bytes(self) -> torch.Tensor:
+        return self.bufs[0] if len(self.bufs) == 1 else torch.cat(self.bufs, dim=1)
+
+    def as_transposed_tensor(self) -> Float8Tensor:
+        from ._lib import api
+        from .tensor import TensorWrapper, current_stream_ptr
+        M = self.bufs[0].shape[0]
+        K = self.pts[-1][1]
+        xt = torch.empty((K, M), dtype=torch.uint8, device=self.bufs[0].device)
+        for buf, (k0, k1) in zip(self.bufs, self.pts):
+            wi = TensorWrapper().set_rowwise_data(buf, self.like._fp8_dtype)
+            wo = TensorWrapper().set_rowwise_data(xt[k0:k1], self.like._fp8_dtype)
+            api.nvte_transpose(wi.handle, wo.handle, current_stream_ptr())
+            wi.destroy(); wo.destroy()
+        return Float8Tensor(shape=(M, K), dtype=self.like.dtype, data=None, fp8_scale_inv=self.like._scale_inv,
+                            fp8_dtype=self.like._fp8_dtype, data_transpose=xt)
+
+
+class ColumnParallelLayerNormLinearSP(ColumnParallelLinearSP):
+    """BASELINE configs[3]: LayerNormLinear, column-parallel + sequence-parallel (ref
+    pytorch/module/layernorm_linear.py with parallel_mode="column", sequence_parallel=True).  Each rank
+    normalizes ITS tokens and writes the GEMM's FP8 operand directly (norm + quantize fused for delayed
+    scaling / MXFP8), the FP8 bytes are all-gathered, the GEMM runs on the full token set; backward
+    reduce-scatters dgrad to the local tokens and runs the norm backward there.  dgamma / dbeta are
+    the LOCAL tokens' sums: with sequence parallelism the framework all-reduces them over the TP group
+    (Megatron's `sequence_parallel` parameter attribute); `allreduce_norm_grads=True` does it here."""
+
+    def __init__(self, in_features: int, out_features: int, tp: int, rank: int, recipe=None, device=None,
+                 group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2,
+                 normalization: str = "RMSNorm", eps: float = 1e-5, zero_centered_gamma: bool = False,
+                 allreduce_norm_grads: bool = False):
+        super().__init__(in_features, out_features, tp, rank, recipe, device, group, params_dtype, overlap, chunks)
+        if normalization not in ("LayerNorm", "RMSNorm"):
+            raise ValueError(f"unsupported normalization {normalization}")
+        self.normalization, self.eps, self.zero_centered_gamma = normalization, eps, zero_centered_gamma
+        self.allreduce_norm_grads = allreduce_norm_grads
+        g0 = torch.zeros if zero_centered_gamma else torch.ones
+        self.layer_norm_weight = g0(in_features, dtype=params_dtype, device=self.device)
+        self.layer_norm_bias = (torch.zeros(in_features, dtype=params_dtype, device=self.device)
+                                if normalization == "LayerNorm" else None)
+
+    def forward(self, x_local: torch.Tensor, is_first_microbatch=None):
+        from .linear import FWD_INPUT
+        from .normalization import layernorm_fwd, rmsnorm_fwd
+        st = self.state
+        w8 = self._cached_weight(is_first_microbatch)
+        qi = st.fwd_q[FWD_INPUT]
+        if isinstance(qi, MXFP8Quantizer):
+            qi.set_usage(rowwise=True, columnwise=True)
+        else:
+            qi.set_usage(rowwise=True, columnwise=False)
+        x2d = x_local.reshape(-1, x_local.shape[-1])
+        if self.normalization == "LayerNorm":
+            ln8, mu, rsigma = layernorm_fwd(x2d, self.layer_norm_weight, self.layer_norm_bias, self.eps,
+                                            quantizer=qi, zero_centered_gamma=self.zero_centered_gamma)
+        else:
+            ln8, mu, rsigma = rmsnorm_fwd(x2d, self.layer_norm_weight, self.eps, quantizer=qi,
+                                          zero_centered_gamma=self.zero_centered_gamma)
+        y, x8 = self._gather_and_gemm(ln8, w8, x2d.shape[0])
+        st.update_fwd(self.group)
+        return y, (x8, w8, x2d, mu, rsigma)
+
+    def backward(self, dy: torch.Tensor, saved):
+        from .normalization import layernorm_bwd, rmsnorm_bwd
+        x8, w8, x2d, mu, rsigma = saved
+        dln_local, dw = self._backward_gemms(dy, (x8, w8))
+        dln_local = dln_local.to(self.layer_norm_weight.dtype)
+        if self.normalization == "LayerNorm":
+            dx, dgamma, dbeta = layernorm_bwd(dln_local, x2d, mu, rsigma, self.layer_norm_weight,
+                                              zero_centered_gamma=self.zero_centered_gamma)
+        else:
+            dx, dgamma = rmsnorm_bwd(dln_local, x2d, rsigma, self.layer_norm_weight,
+                                     zero_centered_gamma=self.zero_centered_gamma)
+            dbeta = None
+        if self.allreduce_norm_grads and self.tp > 1:
+            for t in (dgamma, dbeta):
+                if t is not None:
+                    _all_reduce_sum_(t, self.group)
+        self.state.update_bwd(self.group)
+        return dx, dw, dgamma, dbeta
+
+    def step(self, x_local, dy, is_first_microbatch=None):
+        y, saved = self.forward(x_local, is_first_microbatch)
+        dx, dw, dgamma, dbeta = self.backward(dy, saved)
+        return y, dx, dw, dgamma, dbeta
+
+
+def _all_reduce_sum_(t: torch.Tensor, group) -> None:
+    if _is_gloo(group) and t.is_cuda:
+        h = t.float().cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h.to(t.dtype))
+    else:
+        dist.all_reduce(t, group=group)
+
+
+# ---------------------------------------------------------------------------------------
+# row-parallel + sequence-parallel Linear (ref module/linear.py:539-549 forward reduce-scatter,
+# module/base.py:1680-1684 FP8 all-gather of dY in backward)
+# ---------------------------------------------------------------------------------------
+class RowParallelLinearSP:
+    """Weight shard [N, K/tp].  forward: the input holds ALL tokens but only this rank's K/tp features
+    (the output of a column-parallel layer); Y partial sums [M, N] are reduce-scattered to the token
+    shard, the GEMM cut along N so that piece j's reduce-scatter runs under GEMM j+1.  backward: dY
+    [M/tp, N] is quantized with a group-wide scale, all-gathered in FP8 (transpose rebuilt locally),
+    dgrad and wgrad run on the full token set without further communication."""
+
+    def __init__(self, in_features: int, out_features: int, tp: int, rank: int, recipe=None, device=None,
+                 group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2):
+        from .linear import BWD_GRAD_OUTPUT, LinearFP8State
+        assert in_features % tp == 0
+        self.K_local, self.N, self.tp, self.rank, self.group = in_features // tp, out_features, tp, rank, group
+        self.device = device or torch.device("cuda")
+        g = torch.Generator(device="cpu").manual_seed(8765 + rank)
+        self.weight = (torch.randn(out_features, self.K_local, generator=g) * 0.02).to(params_dtype).to(self.device)
+        self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device)
+        self.overlap, self.chunks, self.out_dtype = overlap, chunks, params_dtype
+        # dY is sharded on tokens and gathered in FP8: one scale over the whole group
+        configure_amax_reduction(self.state.bwd_q[BWD_GRAD_OUTPUT], group)
+
+    def forward(self, x: torch.Tensor, is_first_microbatch=None):
+        from .gemm import general_gemm
+        from .linear import FWD_INPUT, FWD_WEIGHT
+        st = self.state
+        qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
+        if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
+            qw.set_usage(rowwise=True, columnwise=True)
+            st.weight_cache = qw(self.weight)
+        w8 = st.weight_cache
+        qi.set_usage(rowwise=True, columnwise=True)
+        x8 = qi(x)
+        M = x.shape[0]
+        if self.overlap and self.tp > 1 and isinstance(w8, Float8Tensor):
+            def cols_gemm(c0, c1):
+                wj = Float8Tensor(shape=(c1 - c0, self.K_local), dtype=w8.dtype, data=w8._data[c0:c1],
+                                  fp8_scale_inv=w8._scale_inv, fp8_dtype=w8._fp8_dtype)
+                out, *_ = general_gemm(wj, x8, out_dtype=self.out_dtype, layout="TN")
+                return out
+            y_local = gemm_and_reduce_scatter_nchunked(self.N, cols_gemm, self.group, self.chunks)
+        else:
+            y_partial, *_ = general_gemm(w8, x8, out_dtype=self.out_dtype, layout="TN")
+            y_local, _ = reduce_scatter_along_first_dim(y_partial, self.group)
+        st.update_fwd(self.group)
+        return y_local, (x8, w8)
+
+    def backward(self, dy_local: torch.Tensor, saved):
+        from .gemm import general_gemm
+        from .linear import BWD_GRAD_OUTPUT
+        x8, w8 = saved
+        st = self.state
+        qg = st.bwd_q[BWD_GRAD_OUTPUT]
+        dy8 = gather_along_first_dim(dy_local.reshape(-1, dy_local.shape[-1]), self.group, quantizer=qg,
+                                     need_transpose=True)      # ref base.py:1680-1684
+        dx, *_ = general_gemm(w8, dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
+        dw, *_ = general_gemm(x8, dy8, out_dtype=self.out_dtype, layout="NT", grad=True)
+        st.update_bwd(self.group)
+        return dx, dw
+
+    def step(self, x, dy_local, is_first_microbatch=None):
+        y, saved = self.forward(x, is_first_microbatch)
+        dx, dw = self.backward(dy_local, saved)
         return y, dx, dw

@@ -467,9 +467,9 @@ class Float8CurrentScalingQuantizer(Quantizer):
         cfg = QuantizationConfig(self.force_pow_2_scales, self.amax_epsilon, wn)
         api.nvte_compute_amax_with_config(wi.handle, wo.handle, cfg.handle, stream)
         if self.with_amax_reduction:
-            import torch.distributed as dist
-            # blocking MAX all-reduce of one float (ref csrc/quantizer.cpp:994-999)
-            dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=self.amax_reduction_group)
+            # MAX all-reduce of one float over the group the tensor is sharded on (ref csrc/quantizer.cpp:994-999)
+            from .distributed import all_reduce_max_
+            all_reduce_max_(amax, self.amax_reduction_group)
         api.nvte_compute_scale_from_amax(wo.handle, cfg.handle, stream)
         wo.clear_amax()  # avoid the atomic amax update in the cast (quantizer.cpp:1006)
         api.nvte_quantize_v2(wi.handle, wo.handle, cfg.handle, stream)
