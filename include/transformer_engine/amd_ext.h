@@ -46,6 +46,17 @@ void nvte_amd_delayed_scaling_after_reduction(const NVTETensor amax_reduction_bu
 void nvte_amd_set_columnwise_transposed(NVTETensor tensor, int transposed);
 int nvte_amd_get_columnwise_transposed(const NVTETensor tensor);
 
+/* The same for a grouped MXFP8 tensor (no counterpart in the reference): columnwise_data holds every
+ * member's payload transposed ([last, first_i] at the member's element offset) and
+ * columnwise_scale_inv the members' [pad128(last), pad4(first_i / 32)] scale matrices back to back
+ * (member i at the sum of the padded sizes before it - the offset rule of ref
+ * gemm/cublaslt_grouped_gemm.cu:1117-1198).  nvte_group_quantize writes this layout when the flag is set
+ * and nvte_grouped_gemm* needs it for the NN / NT layouts (dgrad / wgrad).  Member first dims must be
+ * multiples of 128 for grouped MXFP8 tensors (the reference states the same for the logical first dim,
+ * cast/mxfp8/group_quantize_mxfp8.cuh:842, and its swizzled-scale offsets assume it per member). */
+void nvte_amd_set_grouped_columnwise_transposed(NVTEGroupedTensor tensor, int transposed);
+int nvte_amd_get_grouped_columnwise_transposed(const NVTEGroupedTensor tensor);
+
 /* Library identification: "transformerengine_amd <version> gfx950". */
 const char *nvte_amd_version(void);
 

@@ -37,7 +37,13 @@ void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
  * output's per-tensor `scale` array (FP8 per-tensor scaling); rowwise bytes keep the flat layout,
  * columnwise bytes are each member's transpose at the member's own offset.  Shapes are read on the
  * device (first_dims / last_dims / tensor_offsets), honours the config's noop flag.  amax and
- * scale_inv are NOT touched (nvte_group_compute_amax_with_config / _scale_from_amax own them). */
+ * scale_inv are NOT touched (nvte_group_compute_amax_with_config / _scale_from_amax own them).
+ * MXFP8 grouped output (ref cast/dispatch/quantize.cuh:470 -> cast/mxfp8/group_quantize_mxfp8.cuh):
+ * same-shape and varying-first-dim groups, member first dims and the last dim multiples of 128; the
+ * group is quantized as ONE [sum first, last] tensor as in the reference (rowwise scales at the
+ * member's global rows); columnwise output in the reference layout or, if
+ * nvte_amd_set_grouped_columnwise_transposed() was set on `output`, per-member transposed (amd_ext.h);
+ * compact or GEMM-swizzled scales per output's with_gemm_swizzled_scales. */
 void nvte_group_quantize(const NVTEGroupedTensor input, NVTEGroupedTensor output,
                          const NVTEQuantizationConfig quant_config, hipStream_t stream);
 /* ref cast.h:429 */

@@ -101,7 +101,10 @@ size_t nvte_get_grouped_gemm_setup_workspace_size(size_t num_tensors);
 
 /* ref gemm.h:388.  D[i] = alpha[i] * op(A[i]) op(B[i]) + beta[i] * C[i] for every member i, ONE
  * persistent launch; member shapes are read on the device.  FP8 per-tensor scaling operands
- * (scale_inv[i] per member), BF16/FP16/FP32 C and D.  C may be NULL (beta is then ignored) or D. */
+ * (scale_inv[i] per member) or MXFP8 operands (both A and B; ref cublaslt_grouped_gemm.cu:283-300; member
+ * i's e8m0 scale matrix at the sum of the padded sizes before it, :1117-1198; compact or swizzled;
+ * layouts that contract over a member's first dim need the transposed columnwise storage of
+ * amd_ext.h), BF16/FP16/FP32 C and D.  C may be NULL (beta is then ignored) or D. */
 void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
                        const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
                        const NVTETensor beta, NVTETensor workspace_setup, NVTETensor workspace_cublas,
@@ -109,7 +112,7 @@ void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedT
 /* NO counterpart in the reference.  nvte_grouped_gemm for callers that cannot allocate device memory
  * or carry a workspace: code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc.  Same arguments minus the two workspaces: the per-member records + tile prefix live in a
- * static device array of this library (about 17 KiB per GPU, held until the process ends) whose
+ * static device array of this library (about 26 KiB per GPU, held until the process ends) whose
  * address is resolved once per device (at nvte_cublas_handle_init() or at the first call on that
  * device).  The call allocates nothing.  Limits: at most nvte_amd_grouped_gemm_noalloc_max_tensors()
  * (256) member tensors, more is an error; every call on a GPU shares that GPU's array, so two calls

@@ -81,6 +81,8 @@ _SIGS = {
     "nvte_amd_clear_error": (_V, []),
     "nvte_amd_version": (C.c_char_p, []),
     "nvte_amd_set_columnwise_transposed": (_V, [_P, _I]),
+    "nvte_amd_set_grouped_columnwise_transposed": (_V, [_P, _I]),
+    "nvte_amd_get_grouped_columnwise_transposed": (_I, [_P]),
     "nvte_amd_get_columnwise_transposed": (_I, [_P]),
     "nvte_amd_delayed_scaling_after_reduction": (_V, [_P, C.POINTER(_P), C.POINTER(_P), _SZ, C.c_char_p, _I, _F, _P]),
     # transformer_engine.h

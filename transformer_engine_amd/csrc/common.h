@@ -217,6 +217,9 @@ struct GroupedTensor {
   size_t num_tensors = 0;
   NVTEShape logical_shape{{0}, 1};
   bool with_gemm_swizzled_scales = false;
+  // MXFP8 extension (amd_ext.h): columnwise_data holds each member's payload TRANSPOSED ([last, first_i] at
+  // the member's own offset) with scales [pad128(last), pad4(first_i / 32)] per member, back to back
+  bool columnwise_transposed = false;
   bool live = false;
 
   bool has_data() const { return data.present(); }

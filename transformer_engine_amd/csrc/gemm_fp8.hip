@@ -81,6 +81,7 @@ struct GemmArgs {
   // grouped launch (kernel variant GROUPED = true only): per-member problems + tile prefix,
   // both written on the device by grouped_setup_kernel
   const struct GroupDesc *groups;
+  const struct GroupScaleDesc *group_scales;  // MX members only: where each member's e8m0 scales sit
   const unsigned *group_tile_start;  // [num_groups + 1]
   unsigned num_groups;
 #ifdef TE_GEMM_STAMPS
@@ -111,6 +112,13 @@ struct GroupDesc {
   float beta;
   unsigned n, m, k;
   unsigned tiles_j;
+};
+
+// MXFP8 members: the e8m0 scale matrices of the member's P and Q operands (device-written)
+struct GroupScaleDesc {
+  const uint8_t *eP, *eQ;
+  unsigned eP_stride, eQ_stride;  // bytes per scale row: pad4(ceil(k / 32))
+  unsigned eP_bytes, eQ_bytes;    // padded size of the member's scale matrix
 };
 
 constexpr int kEpiNone = 0;
@@ -200,7 +208,7 @@ __device__ __forceinline__ void store_any(void *p, size_t idx, int dtype, float 
 // staging in the main loop, 2: no LDS fragment reads, 3: neither (MFMA + barrier only).  Results are wrong.
 template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, bool EPI, bool GROUPED = false, int ABL = 0>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
-  static_assert(!(GROUPED && (MX || EPI)), "the grouped variant is per-tensor-scaled FP8 without epilogues");
+  static_assert(!(GROUPED && EPI), "the grouped variant has no extended epilogues");
   // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
   constexpr int kScaleBase = 2 * kStageBytes;
   constexpr int kEpiBase = kScaleBase + (MX ? 2 * kScaleSlotBytes : 0);
@@ -246,6 +254,9 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     unsigned pbytes, qbytes;     // bytes the tile's descriptors may touch (0 = everything reads 0)
     unsigned i0, j0;
     unsigned ss;                 // MX: scalar part of this wave's scale source address (K tile 0)
+    // GROUPED && MX: the member's scale matrix this wave stages from (P's for waves 0-3, Q's for 4-7)
+    const uint8_t *eb;
+    unsigned ebytes, estride;    // (all wave-uniform: the lane part of the address is rebuilt per K tile)
     // GROUPED only: the member's own problem
     unsigned n, m, k;
     float mult, beta;
@@ -298,6 +309,16 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       t.qbase = const_cast<uint8_t *>(d.Q) + static_cast<size_t>(t.j0) * d.k;
       t.pbytes = rows_p * d.k;
       t.qbytes = rows_q * d.k;
+      if constexpr (MX) {
+        const GroupScaleDesc &sd = a.group_scales[grp];
+        const unsigned stride = wave < 4 ? sd.eP_stride : sd.eQ_stride;
+        t.eb = wave < 4 ? sd.eP : sd.eQ;
+        t.ebytes = valid ? (wave < 4 ? sd.eP_bytes : sd.eQ_bytes) : 0u;
+        t.estride = stride;
+        const unsigned tile_row0 = wave < 4 ? t.i0 : t.j0;
+        t.ss = e_swz ? ((tile_row0 / 128 + ((wave & 3u) >> 1)) * (stride / 4)) * 512 + (wave & 1u) * 256
+                     : (tile_row0 + (wave & 3u) * 64) * stride;
+      }
       return t;
     }
 #ifdef TE_GEMM_STAMPS
@@ -442,10 +463,11 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   }
   auto stage_scales = [&](const TileCtx &t, unsigned slot, unsigned kt) {
     if constexpr (MX) {
-      const __amdgpu_buffer_rsrc_t re =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(e_base), 0, e_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<uint8_t *>(GROUPED ? t.eb : e_base), 0, GROUPED ? t.ebytes : e_bytes, 0x00020000);
       lds_u8 *dst = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + wave * 256);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4, sv,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4,
+                                               GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv,
                                                t.ss + kt * (e_swz ? 512u : 4u), 0, 0);
     }
   };
@@ -454,11 +476,11 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // padded scale buffer holds: force 2^0 there (their payload bytes are zero-filled).
   // Branch-free on purpose: a branch in the main loop lets the optimiser sink the MFMAs out of
   // their place in the pipeline.
-  auto commit_scales = [&](unsigned slot, unsigned kt) {
+  auto commit_scales = [&](unsigned slot, unsigned kt, unsigned kdim) {
     if constexpr (MX) {
       const uint8_t *img = lds + kScaleBase + slot * kScaleSlotBytes;
-      const unsigned kbase = min(kt * BK, a.k);
-      const unsigned valid = min(4u, (a.k - kbase + 31) / 32);
+      const unsigned kbase = min(kt * BK, kdim);
+      const unsigned valid = min(4u, (kdim - kbase + 31) / 32);
       const uint32_t keep = valid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * valid)) - 1u);
       const uint32_t fill = 0x7F7F7F7Fu & ~keep;
 #pragma unroll
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // K tile two ahead (`st` / `st_k0`: which output tile and which K offset that is) + the MX
   // scale hand-over.  `g` counts K tiles across output tiles and picks the LDS slot.
   auto k_tile = [&](unsigned g, const TileCtx &st, unsigned st_k0, unsigned st_kt, unsigned commit_kt,
-                    auto prefetch_tag) {
+                    unsigned commit_k, auto prefetch_tag) {
     constexpr bool PREFETCH = decltype(prefetch_tag)::value;  // fetch the next K tile's first fragments
     const unsigned cur = g & 1u, nxt = cur ^ 1u;
     mm(I0{}, I0{}, I0{}, p[0], q[0][0]);
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     mm(I1{}, I3{}, I0{}, p[3], q[1][0]);
     mm(I1{}, I3{}, I1{}, p[3], q[1][1]);
     if constexpr (PREFETCH) rdP(nxt, 0, 3, p[3]);
-    commit_scales(nxt, commit_kt);
+    commit_scales(nxt, commit_kt, commit_k);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -755,7 +777,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  commit_scales(0, 0);
+  commit_scales(0, 0, GROUPED ? cur_t.k : a.k);
   auto first_fragments = [&](unsigned slot) {
     rdP(slot, 0, 0, p[0]);
     rdQ(slot, 0, 0, q[0][0]);
@@ -774,13 +796,15 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     const TileCtx next_t = make_tile(next, has_next);
     // K tiles of THIS output tile: the launch's, or the member's (never fewer than two)
     const unsigned nk_t = GROUPED ? max((cur_t.k + BK - 1) / BK, 2u) : nk;
-    for (unsigned kt = 0; kt + 2 < nk_t; ++kt, ++g) k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, std::true_type{});
+    const unsigned k_cur = GROUPED ? cur_t.k : a.k, k_next = GROUPED ? next_t.k : a.k;
+    for (unsigned kt = 0; kt + 2 < nk_t; ++kt, ++g)
+      k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, k_cur, std::true_type{});
     if (nk_t >= 2) {
-      k_tile(g, next_t, 0, 0, nk_t - 1, std::true_type{});
+      k_tile(g, next_t, 0, 0, nk_t - 1, k_cur, std::true_type{});
       ++g;
     }
     // the last K tile leaves the fragment registers dead, so the epilogue has room to work in
-    k_tile(g, next_t, BK, 1, 0, std::false_type{});
+    k_tile(g, next_t, BK, 1, 0, k_next, std::false_type{});
     ++g;
     TE_STAMP();
     epilogue(cur_t);
@@ -1135,7 +1159,9 @@ constexpr int kMaxListed = 64;  // discrete A / C / D lists travel in the kernel
 
 struct GroupedOperandMeta {
   const uint8_t *base = nullptr;     // payload of the storage picked (null: discrete list)
-  const float *scale_inv = nullptr;  // one entry per member
+  const float *scale_inv = nullptr;  // per-tensor scaling: one entry per member
+  const uint8_t *e8m0 = nullptr;     // MXFP8: the members' scale matrices back to back
+  int k_is_last = 1;                 // MXFP8: 1 = rowwise storage, 0 = per-member transposed columnwise
   GroupShapes shapes;
 };
 struct GroupedOutMeta {
@@ -1167,9 +1193,40 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
                                                            const ListedInputs la, const ListedOutputs lo,
                                                            const float *alpha, int alpha_n, const float *beta,
                                                            int beta_n, unsigned G, int transa, int transb,
-                                                           unsigned d_elem_bytes, int has_c) {
+                                                           unsigned d_elem_bytes, int has_c, GroupScaleDesc *sdescs) {
   const unsigned lane = threadIdx.x;
   const unsigned per = (G + 63) / 64, lo_i = lane * per, hi_i = min(lo_i + per, G);
+  const bool mx = sdescs != nullptr;
+  // MXFP8: member i's scale matrix starts at the sum of the PADDED sizes of the members before it
+  // (ref cublaslt_grouped_gemm.cu:1117-1198 compute_grouped_scale_inv_offset): [pad128(rows), pad4(k/32)]
+  // with rows x k the member's K-contiguous view (rowwise storage, or the transposed columnwise one).
+  auto scale_dims = [](const GroupedOperandMeta &o, int64_t first, int64_t last, unsigned &stride, unsigned &bytes) {
+    const int64_t rows = o.k_is_last ? first : last, kk = o.k_is_last ? last : first;
+    stride = static_cast<unsigned>(((kk + 31) / 32 + 3) / 4 * 4);
+    bytes = static_cast<unsigned>((rows + 127) / 128 * 128) * stride;
+  };
+  unsigned a_sc_run = 0, b_sc_run = 0;
+  if (mx) {
+    unsigned a_loc = 0, b_loc = 0;
+    for (unsigned i = lo_i; i < hi_i; ++i) {
+      int64_t f, l, o;
+      unsigned st, by;
+      member_dims(A.shapes, i, f, l, o);
+      scale_dims(A, f, l, st, by);
+      a_loc += by;
+      member_dims(B.shapes, i, f, l, o);
+      scale_dims(B, f, l, st, by);
+      b_loc += by;
+    }
+    unsigned a_incl = a_loc, b_incl = b_loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned ua = __shfl_up(a_incl, off, 64), ub = __shfl_up(b_incl, off, 64);
+      if (lane >= static_cast<unsigned>(off)) { a_incl += ua; b_incl += ub; }
+    }
+    a_sc_run = a_incl - a_loc;
+    b_sc_run = b_incl - b_loc;
+  }
   unsigned local = 0;
   for (unsigned i = lo_i; i < hi_i; ++i) {
     int64_t a_first, a_last, a_off = 0, b_first, b_last, b_off, d_first, d_last, d_off = 0;
@@ -1178,7 +1235,7 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     if (A.base) {
       member_dims(A.shapes, i, a_first, a_last, a_off);
       q_ptr = A.base + a_off;
-      q_scale = A.scale_inv + i;
+      q_scale = mx ? nullptr : A.scale_inv + i;
     } else {
       a_first = la.first[i];
       a_last = la.last[i];
@@ -1206,7 +1263,7 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     const int64_t n = transb ? b_last : b_first, kb = transb ? b_first : b_last;
     // the stores follow D's own shape; anything inconsistent (or a K the 16-byte loads cannot take)
     // turns the member's output into NaN instead of reading out of bounds
-    const bool ok = d_first == n && d_last == m && ka == kb && ka % 16 == 0 && ka <= (1 << 23);
+    const bool ok = d_first == n && d_last == m && ka == kb && ka % (mx ? 32 : 16) == 0 && ka <= (1 << 23);
     GroupDesc d;
     d.P = B.base + b_off;
     d.Q = q_ptr;
@@ -1215,7 +1272,19 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     d.n = static_cast<unsigned>(d_first);
     d.m = static_cast<unsigned>(d_last);
     d.k = ok ? static_cast<unsigned>(ka) : 0u;
-    d.mult = ok ? alpha[alpha_n > 1 ? i : 0] * B.scale_inv[i] * *q_scale : __builtin_nanf("");
+    if (mx) {
+      GroupScaleDesc sd;
+      scale_dims(B, b_first, b_last, sd.eP_stride, sd.eP_bytes);
+      scale_dims(A, a_first, a_last, sd.eQ_stride, sd.eQ_bytes);
+      sd.eP = B.e8m0 + b_sc_run;
+      sd.eQ = A.e8m0 + a_sc_run;
+      b_sc_run += sd.eP_bytes;
+      a_sc_run += sd.eQ_bytes;
+      sdescs[i] = sd;
+      d.mult = ok ? alpha[alpha_n > 1 ? i : 0] : __builtin_nanf("");
+    } else {
+      d.mult = ok ? alpha[alpha_n > 1 ? i : 0] * B.scale_inv[i] * *q_scale : __builtin_nanf("");
+    }
     d.beta = has_c ? beta[beta_n > 1 ? i : 0] : 0.f;
     d.tiles_j = (d.m + BN - 1) / BN;
     descs[i] = d;
@@ -1235,30 +1304,43 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
   if (lane == 63) tile_start[G] = incl;
 }
 
-size_t grouped_setup_bytes(size_t G) { return round_up(G * sizeof(GroupDesc), 256) + (G + 1) * sizeof(unsigned) + 256; }
+// records | tile prefix | MXFP8 scale records (+ 256 to align the caller's pointer)
+size_t grouped_setup_bytes(size_t G) {
+  return round_up(G * sizeof(GroupDesc), 256) + round_up((G + 1) * sizeof(unsigned), 256) +
+         round_up(G * sizeof(GroupScaleDesc), 256) + 256;
+}
 
 // Pick the K-contiguous storage of an FP8 grouped operand ("TN everywhere", like the ungrouped path
 // and ref cublaslt_grouped_gemm.cu:551-565): rowwise when the contraction runs along the member's last
 // dim, else the per-member transposed ("columnwise") copy.
 GroupedOperandMeta pick_grouped_operand(const GroupedTensor &t, bool k_is_last, const char *name, DType &dtype) {
-  NVTE_CHECK(is_tensor_scaling(t.scaling_mode),
-             "Grouped GEMM: only FP8 per-tensor scaling is implemented in this library, ", name, " has ",
+  const bool mx = is_mxfp8(t.scaling_mode);
+  NVTE_CHECK(is_tensor_scaling(t.scaling_mode) || mx,
+             "Grouped GEMM: FP8 per-tensor scaling and MXFP8 are implemented in this library, ", name, " has ",
              scaling_mode_name(t.scaling_mode));
   GroupedOperandMeta m;
+  const void *sinv;
   if (k_is_last) {
     NVTE_CHECK(t.has_data(), "Grouped GEMM: ", name, " is missing row-wise data");
     m.base = static_cast<const uint8_t *>(t.data.ptr);
-    m.scale_inv = static_cast<const float *>(t.scale_inv.ptr);
+    sinv = t.scale_inv.ptr;
     dtype = t.data.dtype;
   } else {
     NVTE_CHECK(t.has_columnwise_data(), "Grouped GEMM: ", name, " is missing column-wise data needed for TN layout");
+    // MXFP8: the contraction runs over the members' stored rows, which the gfx950 MFMA path can only read
+    // from the per-member TRANSPOSED columnwise layout (amd_ext.h) - the twin of the per-tensor rule above
+    NVTE_CHECK(!mx || t.columnwise_transposed, "Grouped GEMM: MXFP8 ", name,
+               " is read along its first dimension: quantize it with the transposed columnwise layout "
+               "(nvte_amd_set_grouped_columnwise_transposed)");
     m.base = static_cast<const uint8_t *>(t.columnwise_data.ptr);
-    m.scale_inv = static_cast<const float *>(t.columnwise_scale_inv.ptr);
+    sinv = t.columnwise_scale_inv.ptr;
     dtype = t.columnwise_data.dtype;
   }
+  m.k_is_last = k_is_last ? 1 : 0;
+  if (mx) m.e8m0 = static_cast<const uint8_t *>(sinv); else m.scale_inv = static_cast<const float *>(sinv);
   NVTE_CHECK(is_fp8(dtype), "Grouped GEMM: this library implements FP8 operands only, ", name, " is ",
              dtype_name(dtype));
-  NVTE_CHECK(m.scale_inv != nullptr, "Grouped GEMM: FP8 input ", name, " requires inverse of scale!");
+  NVTE_CHECK(sinv != nullptr, "Grouped GEMM: FP8 input ", name, " requires inverse of scale!");
   NVTE_CHECK((reinterpret_cast<uintptr_t>(m.base) & 15u) == 0, "Grouped GEMM: ", name, " must be 16-byte aligned");
   m.shapes = group_shapes_of(t);
   return m;
@@ -1300,11 +1382,16 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   NVTE_CHECK(call.B->num_tensors == G, "Grouped GEMM: B must have num_tensors = ", G);
   check_grouped_input(*call.B, "B");
   B = pick_grouped_operand(*call.B, !transb, "B", b_dtype);
+  const bool mx = is_mxfp8(call.B->scaling_mode);
+  bool a_swz = false;
   if (call.A != nullptr) {
     NVTE_CHECK(call.A->num_tensors == G, "Grouped GEMM: A must have num_tensors = ", G);
     check_grouped_input(*call.A, "A");
+    NVTE_CHECK(is_mxfp8(call.A->scaling_mode) == mx, "Grouped GEMM: A and B must both use MXFP8 scaling or both not.");
     A = pick_grouped_operand(*call.A, transa, "A", a_dtype);
+    a_swz = call.A->with_gemm_swizzled_scales;
   } else {
+    NVTE_CHECK(!mx, "Grouped GEMM: a discrete A_list is implemented for FP8 per-tensor scaling only");
     NVTE_CHECK(G <= static_cast<size_t>(kMaxListed), "Grouped GEMM: A_list supports at most ", kMaxListed,
                " tensors, got ", G);
     for (size_t i = 0; i < G; ++i) {
@@ -1377,18 +1464,24 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   const uintptr_t ws_al = (reinterpret_cast<uintptr_t>(ws_ptr) + 255) & ~static_cast<uintptr_t>(255);
   GroupDesc *descs = reinterpret_cast<GroupDesc *>(ws_al);
   unsigned *tile_start = reinterpret_cast<unsigned *>(ws_al + round_up(G * sizeof(GroupDesc), 256));
+  GroupScaleDesc *sdescs = mx ? reinterpret_cast<GroupScaleDesc *>(ws_al + round_up(G * sizeof(GroupDesc), 256) +
+                                                                   round_up((G + 1) * sizeof(unsigned), 256))
+                              : nullptr;
 
   const DeviceInfo &di = device_info();
   hipLaunchKernelGGL(grouped_setup_kernel, dim3(1), dim3(64), 0, stream, descs, tile_start, A, B, C, D, la, lo,
                      static_cast<const float *>(alpha.data.ptr), static_cast<int>(alpha.data.numel()),
                      static_cast<const float *>(beta.data.ptr), static_cast<int>(beta.data.numel()),
                      static_cast<unsigned>(G), transa ? 1 : 0, transb ? 1 : 0,
-                     static_cast<unsigned>(dtype_bits(d_dtype) / 8), has_c);
+                     static_cast<unsigned>(dtype_bits(d_dtype) / 8), has_c, sdescs);
   NVTE_CHECK_HIP(hipGetLastError());
 
   GemmArgs g;
   std::memset(&g, 0, sizeof(g));
   g.groups = descs;
+  g.group_scales = sdescs;
+  g.eP_swz = (mx && call.B->with_gemm_swizzled_scales) ? 1u : 0u;
+  g.eQ_swz = (mx && a_swz) ? 1u : 0u;
   g.group_tile_start = tile_start;
   g.num_groups = static_cast<unsigned>(G);
   g.d_dtype = d_dtype;
@@ -1399,17 +1492,21 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   }
   g.grid = cus;  // persistent: the tile count is only known on the device
   (void)api;
-  launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
+  if (mx)
+    launch_by_format<true, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
+  else
+    launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
 }
 
 // ---- static scratch for nvte_amd_grouped_gemm_noalloc (amd_ext.h) --------------------------------
 // The GroupDesc records + tile prefix of ONE grouped launch of up to kNoAllocMaxGroups members live in
 // a device array of this code object instead of a caller workspace.  Every GPU the library runs on
-// holds its own copy (about 17 KiB) until the process ends.  The array's name is a host-side stand-in:
+// holds its own copy (about 26 KiB) until the process ends.  The array's name is a host-side stand-in:
 // host code only ever uses the per-device address obtained below.
 constexpr size_t kNoAllocMaxGroups = 256;
-constexpr size_t kNoAllocScratchBytes = 256 * 64 /* >= round_up(256 * sizeof(GroupDesc), 256) */ + (256 + 1) * 4 + 256 + 256;
-static_assert(sizeof(GroupDesc) <= 64, "resize kNoAllocScratchBytes");
+constexpr size_t kNoAllocScratchBytes = 256 * 64 /* GroupDesc records */ + 1280 /* tile prefix, 257 x 4 rounded up */ +
+                                        256 * 32 /* GroupScaleDesc records */ + 256 + 256;
+static_assert(sizeof(GroupDesc) <= 64 && sizeof(GroupScaleDesc) <= 32, "resize kNoAllocScratchBytes");
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
 
 constexpr int kMaxDevices = 64;
@@ -1470,7 +1567,7 @@ void nvte_amd_grouped_gemm_noalloc(const NVTEGroupedTensor A, int transa, const 
     const size_t G = call.A->num_tensors;
     NVTE_CHECK(G <= kNoAllocMaxGroups, "nvte_amd_grouped_gemm_noalloc: ", G, " member tensors exceed the static scratch "
                "limit of ", kNoAllocMaxGroups, "; use nvte_grouped_gemm with a caller workspace");
-    static_assert(kNoAllocScratchBytes >= 256 * 64 + (kNoAllocMaxGroups + 1) * sizeof(unsigned) + 256, "scratch too small");
+    static_assert(kNoAllocScratchBytes >= 256 * 64 + 1280 + 256 * 32 + 256 && kNoAllocMaxGroups == 256, "scratch too small");
     // Nothing in the scratch has to start at zero: grouped_setup_kernel rewrites every record and
     // prefix entry of this call's G members before the GEMM kernel (same stream) reads them.
     grouped_gemm_impl("nvte_amd_grouped_gemm_noalloc", call, G, transa != 0, transb != 0, alpha, beta,

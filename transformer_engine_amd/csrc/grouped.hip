@@ -276,6 +276,142 @@ __global__ __launch_bounds__(256) void group_cast_transpose_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------- grouped MXFP8 quantize
+// ref common/cast/mxfp8/group_quantize_mxfp8.cuh (same-shape / varying-first-dim grouped tensors are
+// quantized as ONE [sum first_i, last] tensor there, :478, :795; scales of member i therefore start at
+// global row offsets[i] / last).  One workgroup per 128x128 tile of a member, the thread geometry of
+// mxfp8_tile_kernel (mxfp8.hip): thread t owns rows 8*(t>>4).., columns 8*(t&15).. of the tile, a wave
+// 32 rows = one column block.  Member rows are multiples of 128 by contract (amd_ext.h); rows of a
+// member's last, partial 32-row block are skipped (nothing outside the member is read or written).
+//   ROW  : payload [first_i, last] at the member offset, scales at the member's GLOBAL rows of the
+//          [pad128(sum first), pad4(last/32)] matrix (compact or GEMM-swizzled)
+//   COL  : reference layout - payload un-transposed, scales [sum first / 32, pad128(last)]
+//   TCOL : per-member transposed payload [last, first_i], scales [pad128(last), first_i/32] per member at
+//          pad128(last) * (member's first row / 32) (grouped columnwise_transposed, amd_ext.h)
+__host__ __device__ __forceinline__ size_t mx_swizzled_idx(size_t i, size_t j, size_t tiles_x) {
+  const size_t tile = (i / 128) * tiles_x + (j / 4);
+  const size_t y = i % 128, x = j % 4;
+  return tile * 512 + (y % 32) * 16 + (y / 32) * 4 + x;   // ref common/cast/mxfp8/swizzle.cuh:30-41
+}
+
+template <typename IT, Fp8 F, bool ROW, bool COL, bool TCOL, bool SWZ>
+__global__ __launch_bounds__(256) void group_mxfp8_kernel(
+    const IT *__restrict__ in, uint8_t *__restrict__ out_row, uint8_t *__restrict__ out_col,
+    uint8_t *__restrict__ sc_row, uint8_t *__restrict__ sc_col, const float *__restrict__ noop,
+    const GroupShapes g, const size_t total_rows, const size_t stride_r, const size_t pad_cols,
+    const size_t sc_col_cap) {
+  if (noop_set(noop)) return;
+  __shared__ __attribute__((aligned(16))) uint8_t tile_t[TCOL ? kTile * kTile : 16];
+  constexpr float rcp_max = 1.0f / Fp8Traits<F>::max_finite;
+  unsigned mem, lt;
+  if (!locate_tile(g, blockIdx.x, mem, lt)) return;
+  const Member m = member_of(g, mem);
+  const size_t rows = static_cast<size_t>(m.rows), cols = static_cast<size_t>(m.cols);
+  const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
+  const size_t tile_r = lt / tiles_c, tile_col = lt % tiles_c;
+  const size_t row_start = static_cast<size_t>(m.off) / cols;  // the member's first row in the group
+
+  const unsigned t = threadIdx.x, cg = t & 15u, rg = t >> 4, w = t >> 6;
+  const size_t row0 = tile_r * kTile + rg * 8, col0 = tile_col * kTile + cg * 8;
+  const bool live = tile_r * kTile + (w + 1) * 32 <= rows;  // wave-uniform: this wave's 32-row block exists
+  const IT *src = in + m.off;
+
+  float f[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (live) {
+      Load8<IT>::run(src + (row0 + i) * cols + col0, f[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.f;
+    }
+  }
+
+  if constexpr (ROW) {
+    uint8_t *dst = out_row + m.off;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float mx = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, __builtin_fabsf(f[i][j]));
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      const uint8_t e = float_to_e8m0(mx * rcp_max);
+      const float r = e8m0_rcp(e);
+      u32x2 q = {cvt4_fp8<F>(f[i][0] * r, f[i][1] * r, f[i][2] * r, f[i][3] * r),
+                 cvt4_fp8<F>(f[i][4] * r, f[i][5] * r, f[i][6] * r, f[i][7] * r)};
+      if (live) *reinterpret_cast<u32x2 *>(dst + (row0 + i) * cols + col0) = q;
+      uint32_t e32 = e;
+      const uint32_t e1 = __shfl_down(e32, 4, 64);
+      const uint32_t e2 = __shfl_down(e32, 8, 64);
+      const uint32_t e3 = __shfl_down(e32, 12, 64);
+      if (cg == 0 && live) {
+        const uint32_t packed = e32 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+        const size_t r_idx = row_start + row0 + i, c_idx = tile_col * 4;
+        const size_t idx = SWZ ? mx_swizzled_idx(r_idx, c_idx, stride_r / 4) : r_idx * stride_r + c_idx;
+        *reinterpret_cast<uint32_t *>(sc_row + idx) = packed;
+      }
+    }
+  }
+
+  if constexpr (COL) {
+    uint32_t qc[8][2];
+    uint32_t ebytes[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float mx = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mx = fmaxf(mx, __builtin_fabsf(f[i][j]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const uint8_t e = float_to_e8m0(mx * rcp_max);
+      ebytes[j >> 2] |= static_cast<uint32_t>(e) << (8 * (j & 3));
+      const float r = e8m0_rcp(e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i][j] *= r;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qc[i][0] = cvt4_fp8<F>(f[i][0], f[i][1], f[i][2], f[i][3]);
+      qc[i][1] = cvt4_fp8<F>(f[i][4], f[i][5], f[i][6], f[i][7]);
+      if constexpr (!TCOL) {
+        u32x2 q = {qc[i][0], qc[i][1]};
+        if (live) *reinterpret_cast<u32x2 *>(out_col + m.off + (row0 + i) * cols + col0) = q;
+      }
+    }
+    if constexpr (TCOL) {
+      const size_t rows_left = rows - tile_r * kTile;
+      store_tile_transposed<true>(tile_t, qc, t, out_col + m.off + (tile_col * kTile) * rows + tile_r * kTile, rows,
+                                  static_cast<unsigned>(rows_left >= kTile ? 8 : rows_left / 32 * 2), kTile);
+    }
+    if (live && (t & 63u) < 16u) {  // rg_local == 0 holds the wave's 32-row block scale for 8 columns
+      if constexpr (TCOL) {
+        const size_t sb = pad_cols * (row_start / 32);
+        const size_t blk = tile_r * 4 + w;                      // block inside the member
+        const size_t stride_c = (rows / 32 + 3) / 4 * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const size_t idx = sb + (SWZ ? mx_swizzled_idx(col0 + j, blk, stride_c / 4) : (col0 + j) * stride_c + blk);
+          // (members that break the 128-row contract could otherwise run past the buffer)
+          if (idx < sc_col_cap) sc_col[idx] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
+        }
+      } else {
+        const size_t blk = (row_start + tile_r * kTile) / 32 + w;  // block of the whole group
+        if constexpr (SWZ) {
+          const size_t tiles_x = ceil_div_dev(ceil_div_dev(total_rows, 32), 4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            sc_col[mx_swizzled_idx(col0 + j, blk, tiles_x)] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
+        } else {
+          u32x2 v = {ebytes[0], ebytes[1]};
+          *reinterpret_cast<u32x2 *>(sc_col + blk * pad_cols + col0) = v;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- grouped dequantize / bias add
 template <Fp8 F, typename OT>
 __global__ __launch_bounds__(256) void group_dequant_kernel(const uint8_t *__restrict__ in, OT *__restrict__ out,
@@ -312,6 +448,81 @@ __global__ __launch_bounds__(256) void group_bias_add_kernel(T *__restrict__ out
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 const float *noop_of(const NVTEQuantizationConfig config) { return noop_ptr_of(static_cast<const QuantConfig *>(config)); }
+
+// MXFP8 branch of nvte_group_quantize (ref cast/dispatch/quantize.cuh:470-471 -> mxfp8::group_quantize)
+void group_quantize_mxfp8(const GroupedTensor &in, GroupedTensor &out, const NVTEQuantizationConfig quant_config,
+                                 hipStream_t stream) {
+  NVTE_CHECK(in.num_tensors == out.num_tensors, "Number of input and output tensors must be same.");
+  NVTE_CHECK(in.has_data(), "Cannot quantize tensor without rowwise data.");
+  NVTE_CHECK(is_high_precision(in.data.dtype), "Grouped quantize input must be FP32/BF16/FP16");
+  NVTE_CHECK(is_fp8(out.dtype()), "Output must have FP8 type.");
+  const bool rowwise = out.has_data(), colwise = out.has_columnwise_data();
+  NVTE_CHECK(rowwise || colwise, "Either rowwise or columnwise output data need to be allocated.");
+  NVTE_CHECK(out.all_same_last_dim(),
+             "Grouped MXFP8 quantization is implemented for same-shape and varying-first-dimension grouped tensors");
+  NVTE_CHECK(in.logical_shape.data[1] == out.logical_shape.data[1] && in.logical_shape.data[0] == out.logical_shape.data[0],
+             "Grouped MXFP8 input and output must have the same logical shape.");
+  NVTE_CHECK(out.num_tensors <= kMaxMembers, "at most ", kMaxMembers, " member tensors are supported");
+  const size_t R = out.logical_shape.data[0], C = out.logical_shape.data[1], T = out.num_tensors;
+  // ref group_quantize_mxfp8.cuh:842 (first logical dim) and :846 (last dim)
+  NVTE_CHECK(R % 128 == 0, "First logical dimension of a grouped MXFP8 tensor must be divisible by 128, got ", R);
+  NVTE_CHECK(C % 128 == 0, "Last dimension of a grouped MXFP8 tensor must be divisible by 128, got ", C);
+  const GroupShapes g = group_shapes_of(out);
+  size_t tiles;
+  if (out.all_same_shape()) {
+    NVTE_CHECK(R % T == 0, "First logical dimension must be divisible by num_tensors.");
+    NVTE_CHECK((R / T) % 128 == 0, "Member first dimension of a grouped MXFP8 tensor must be divisible by 128, got ", R / T);
+    tiles = (R / kTile) * (C / kTile);
+  } else {
+    NVTE_CHECK(g.offsets && g.first_dims,
+               "Varying first-dimension grouped MXFP8 quantization requires first_dims and tensor_offsets.");
+    tiles = (R / kTile + T) * (C / kTile);
+  }
+  NVTE_CHECK(tiles < (1ull << 31), "grouped tensor too large");
+  const size_t stride_r = round_up(C / 32, 4), pad_cols = round_up(C, 128);
+  if (rowwise)
+    NVTE_CHECK(out.scale_inv.numel() >= round_up(R, 128) * stride_r, "Grouped MXFP8 rowwise scale_inv holds ",
+               out.scale_inv.numel(), " bytes, need ", round_up(R, 128) * stride_r);
+  if (colwise)
+    NVTE_CHECK(out.columnwise_scale_inv.numel() >= round_up(R / 32, 4) * pad_cols,
+               "Grouped MXFP8 columnwise scale_inv holds ", out.columnwise_scale_inv.numel(), " bytes, need ",
+               round_up(R / 32, 4) * pad_cols);
+  (void)device_info();
+  const float *noop = noop_of(quant_config);
+  uint8_t *orow = static_cast<uint8_t *>(out.data.ptr), *ocol = static_cast<uint8_t *>(out.columnwise_data.ptr);
+  uint8_t *srow = static_cast<uint8_t *>(out.scale_inv.ptr), *scol = static_cast<uint8_t *>(out.columnwise_scale_inv.ptr);
+  NVTE_REQUIRE_DATA(in.data, "grouped quantize input");
+  NVTE_CHECK((!rowwise || (orow && srow)) && (!colwise || (ocol && scol)),
+             "grouped quantize output has shapes but no data pointers");
+  NVTE_CHECK(aligned16(in.data.ptr) && (!orow || aligned16(orow)) && (!ocol || aligned16(ocol)) &&
+                 (!srow || aligned16(srow)) && (!scol || aligned16(scol)),
+             "Grouped MXFP8 quantization needs 16-byte aligned buffers");
+  const bool tcol = colwise && out.columnwise_transposed, swz = out.with_gemm_swizzled_scales;
+  const dim3 grid(static_cast<unsigned>(tiles)), block(256);
+#define TE_GMX_LAUNCH(IT_, F_, R_, C_, T_, S_)                                                              \
+  hipLaunchKernelGGL((group_mxfp8_kernel<IT_, F_, R_, C_, T_, S_>), grid, block, 0, stream,                  \
+                     static_cast<const IT_ *>(in.data.ptr), orow, ocol, srow, scol, noop, g, R, stride_r, pad_cols, \
+                     colwise ? out.columnwise_scale_inv.numel() : 0)
+#define TE_GMX_BY_LAYOUT(IT_, F_)                                                                           \
+  do {                                                                                                      \
+    if (rowwise && tcol) { if (swz) TE_GMX_LAUNCH(IT_, F_, true, true, true, true); else TE_GMX_LAUNCH(IT_, F_, true, true, true, false); } \
+    else if (tcol) { if (swz) TE_GMX_LAUNCH(IT_, F_, false, true, true, true); else TE_GMX_LAUNCH(IT_, F_, false, true, true, false); }      \
+    else if (rowwise && colwise) { if (swz) TE_GMX_LAUNCH(IT_, F_, true, true, false, true); else TE_GMX_LAUNCH(IT_, F_, true, true, false, false); } \
+    else if (rowwise) { if (swz) TE_GMX_LAUNCH(IT_, F_, true, false, false, true); else TE_GMX_LAUNCH(IT_, F_, true, false, false, false); } \
+    else { if (swz) TE_GMX_LAUNCH(IT_, F_, false, true, false, true); else TE_GMX_LAUNCH(IT_, F_, false, true, false, false); }             \
+  } while (0)
+#define TE_GMX_BY_OUT(IT_)                                                                                  \
+  if (out.dtype() == kNVTEFloat8E4M3) TE_GMX_BY_LAYOUT(IT_, Fp8::E4M3); else TE_GMX_BY_LAYOUT(IT_, Fp8::E5M2)
+  switch (in.data.dtype) {
+    case kNVTEBFloat16: TE_GMX_BY_OUT(bf16_t); break;
+    case kNVTEFloat16: TE_GMX_BY_OUT(f16_t); break;
+    default: TE_GMX_BY_OUT(float); break;
+  }
+#undef TE_GMX_BY_OUT
+#undef TE_GMX_BY_LAYOUT
+#undef TE_GMX_LAUNCH
+  NVTE_CHECK_HIP(hipGetLastError());
+}
 
 }  // namespace
 }  // namespace te
@@ -475,8 +686,12 @@ void nvte_group_quantize(const NVTEGroupedTensor input_, NVTEGroupedTensor outpu
     GroupedTensor &out = *lookup_grouped_checked(output_);
     check_grouped_input(in, "input");
     check_grouped_output(out, "output", false);
+    if (is_mxfp8(out.scaling_mode)) {
+      group_quantize_mxfp8(in, out, quant_config, stream);
+      return;
+    }
     NVTE_CHECK(out.scaling_mode == NVTE_DELAYED_TENSOR_SCALING,
-               "nvte_group_quantize: only FP8 per-tensor scaling is implemented in this library, got ",
+               "nvte_group_quantize: FP8 per-tensor scaling and MXFP8 are implemented in this library, got ",
                scaling_mode_name(out.scaling_mode));
     NVTE_CHECK(in.num_tensors == out.num_tensors, "Number of input and output tensors must be same.");
     NVTE_CHECK(in.has_data(), "Cannot quantize tensor without rowwise data.");

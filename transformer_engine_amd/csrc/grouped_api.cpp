@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.h"
+#include "transformer_engine/amd_ext.h"
 #include "transformer_engine/gemm.h"
 
 namespace te {
@@ -249,6 +250,22 @@ void nvte_get_grouped_tensor_param(const NVTEGroupedTensor tensor, NVTEGroupedTe
     } else {
       *static_cast<NVTEBasicTensor *>(buf) = grouped_buf(*t, param)->as_basic();
     }
+  });
+}
+
+void nvte_amd_set_grouped_columnwise_transposed(NVTEGroupedTensor tensor, int transposed) {
+  api_guard("nvte_amd_set_grouped_columnwise_transposed", [&] {
+    GroupedTensor &t = *lookup_grouped_checked(tensor);
+    NVTE_CHECK(is_mxfp8(t.scaling_mode) || !transposed,
+               "columnwise_transposed is an MXFP8 extension (per-tensor scaling always stores the transposes)");
+    t.columnwise_transposed = transposed != 0;
+  });
+}
+
+int nvte_amd_get_grouped_columnwise_transposed(const NVTEGroupedTensor tensor) {
+  return api_guard("nvte_amd_get_grouped_columnwise_transposed", [&]() -> int {
+    if (tensor == nullptr) return 0;
+    return lookup_grouped_checked(tensor)->columnwise_transposed ? 1 : 0;
   });
 }
 

@@ -16,8 +16,8 @@ import torch
 
 from . import _lib
 from ._lib import api
-from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor, QuantizationConfig,
-                     TensorWrapper, current_stream_ptr, te_dtype, wrap_plain)
+from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor, MXFP8Quantizer,
+                     QuantizationConfig, TensorWrapper, current_stream_ptr, te_dtype, wrap_plain)
 
 (kGRowwiseData, kGColumnwiseData, kGScale, kGAmax, kGRowwiseScaleInv, kGColumnwiseScaleInv, kGColumnwiseAmax,
  kGFirstDims, kGLastDims, kGTensorOffsets, kGWithGEMMSwizzledScales) = range(11)
@@ -62,11 +62,21 @@ class GroupedTensor:
     ``first_dims`` / ``last_dims`` are int64 DEVICE tensors (None = uniform), ``tensor_offsets`` the
     int64 device prefix sums with num_tensors + 1 entries (required when a dim varies).  For FP8
     per-tensor scaling ``columnwise_data`` holds each member's TRANSPOSE at the member's own offset
-    and ``scale`` / ``scale_inv`` / ``amax`` have one entry per member."""
+    and ``scale`` / ``scale_inv`` / ``amax`` have one entry per member.  For MXFP8
+    (``scaling_mode=NVTE_MXFP8_1D_SCALING``) the scale buffers are e8m0 bytes: rowwise
+    ``[pad128(sum first), pad4(last/32)]``; columnwise either the reference layout
+    ``[pad4(sum first / 32), pad128(last)]`` next to an un-transposed payload, or - with
+    ``columnwise_transposed`` (amd_ext.h) - per-member transposed payloads ``[last, first_i]`` with
+    ``[pad128(last), first_i/32]`` scale matrices back to back.  Member first dims are multiples of 128."""
 
     def __init__(self, *, num_tensors: int, logical_shape, dtype: torch.dtype, rowwise_data=None,
                  columnwise_data=None, scale_inv=None, columnwise_scale_inv=None, scale=None, amax=None,
-                 first_dims=None, last_dims=None, tensor_offsets=None, fp8_dtype: Optional[DType] = None):
+                 first_dims=None, last_dims=None, tensor_offsets=None, fp8_dtype: Optional[DType] = None,
+                 scaling_mode: int = _lib.NVTE_DELAYED_TENSOR_SCALING, columnwise_transposed: bool = False,
+                 with_gemm_swizzled_scales: bool = False):
+        self.scaling_mode = int(scaling_mode)
+        self.columnwise_transposed = bool(columnwise_transposed)
+        self.with_gemm_swizzled_scales = bool(with_gemm_swizzled_scales)
         self.num_tensors = int(num_tensors)
         self.logical_shape = tuple(int(d) for d in logical_shape)
         self.dtype = dtype
@@ -84,13 +94,21 @@ class GroupedTensor:
         return (self.rowwise_data if self.rowwise_data is not None else self.columnwise_data).device
 
     def wrap(self) -> GroupedTensorWrapper:
-        w = GroupedTensorWrapper(self.num_tensors, self.logical_shape)
+        w = GroupedTensorWrapper(self.num_tensors, self.logical_shape, self.scaling_mode)
         pd = self.fp8_dtype  # None for high-precision payloads
         flat = lambda t: None if t is None else t.reshape(-1)
+        mx = self.scaling_mode == _lib.NVTE_MXFP8_1D_SCALING
+        sd = DType.kFloat8E8M0 if mx else None
         w.set(kGRowwiseData, flat(self.rowwise_data), pd)
         w.set(kGColumnwiseData, flat(self.columnwise_data), pd)
-        w.set(kGRowwiseScaleInv, self.scale_inv)
-        w.set(kGColumnwiseScaleInv, self.columnwise_scale_inv)
+        w.set(kGRowwiseScaleInv, flat(self.scale_inv), sd)
+        w.set(kGColumnwiseScaleInv, flat(self.columnwise_scale_inv), sd)
+        if mx:
+            if self.columnwise_transposed:
+                api.nvte_amd_set_grouped_columnwise_transposed(w.handle, 1)
+            if self.with_gemm_swizzled_scales:
+                flag = C.c_uint8(1)
+                api.nvte_set_grouped_tensor_param(w.handle, kGWithGEMMSwizzledScales, C.byref(flag), 1)
         w.set(kGScale, self.scale)
         w.set(kGAmax, self.amax)
         w.set(kGFirstDims, self.first_dims)
@@ -128,6 +146,8 @@ def group_quantize(tensor: torch.Tensor, quantizer, num_tensors: int, first_dims
         tensor_offsets = splits_to_offsets(first_dims, Ccols)
     fp8 = quantizer.dtype
     numel = R * Ccols
+    if isinstance(quantizer, MXFP8Quantizer):
+        return _group_quantize_mxfp8(tensor, quantizer, num_tensors, first_dims, tensor_offsets, noop_flag)
     out = GroupedTensor(
         num_tensors=num_tensors, logical_shape=(R, Ccols), dtype=tensor.dtype, fp8_dtype=fp8,
         rowwise_data=torch.empty(numel, dtype=torch.uint8, device=dev) if quantizer.rowwise_usage else None,
@@ -151,8 +171,8 @@ def group_quantize(tensor: torch.Tensor, quantizer, num_tensors: int, first_dims
             cfg = QuantizationConfig(quantizer.force_pow_2_scales, quantizer.amax_epsilon, wn)
             api.nvte_group_compute_amax_with_config(wi.handle, wo.handle, cfg.handle, stream)
             if quantizer.with_amax_reduction:
-                import torch.distributed as dist
-                dist.all_reduce(out.amax, op=dist.ReduceOp.MAX, group=quantizer.amax_reduction_group)
+                from .distributed import all_reduce_max_
+                all_reduce_max_(out.amax, quantizer.amax_reduction_group)
             api.nvte_group_compute_scale_from_amax(wo.handle, cfg.handle, stream)
             api.nvte_group_quantize(wi.handle, wo.handle, cfg.handle, stream)
         elif isinstance(quantizer, Float8Quantizer):
@@ -168,6 +188,41 @@ def group_quantize(tensor: torch.Tensor, quantizer, num_tensors: int, first_dims
         else:
             raise NotImplementedError(f"group_quantize: {type(quantizer).__name__} is not implemented "
                                       "(FP8 per-tensor scaling only)")
+    finally:
+        wi.destroy(); wo.destroy()
+        if wn is not None:
+            wn.destroy()
+    return out
+
+
+def _pad(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _group_quantize_mxfp8(tensor, quantizer: MXFP8Quantizer, num_tensors, first_dims, tensor_offsets, noop_flag):
+    """MXFP8 branch (ref cast/mxfp8/group_quantize_mxfp8.cuh through nvte_group_quantize): same-shape or
+    varying-first-dim members, member rows multiples of 128, one launch, member shapes read on the device."""
+    R, Ccols = tensor.shape
+    dev = tensor.device
+    if R % 128 or Ccols % 128:
+        raise ValueError(f"grouped MXFP8 needs 128-multiple dims, got {R}x{Ccols}")
+    row, col = quantizer.rowwise_usage, quantizer.columnwise_usage
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    out = GroupedTensor(
+        num_tensors=num_tensors, logical_shape=(R, Ccols), dtype=tensor.dtype, fp8_dtype=quantizer.dtype,
+        scaling_mode=_lib.NVTE_MXFP8_1D_SCALING, columnwise_transposed=col and quantizer.columnwise_transposed,
+        with_gemm_swizzled_scales=quantizer.optimize_for_gemm,
+        rowwise_data=u8(R * Ccols) if row else None, columnwise_data=u8(R * Ccols) if col else None,
+        scale_inv=u8(_pad(R, 128) * _pad(Ccols // 32, 4)) if row else None,
+        columnwise_scale_inv=u8(_pad(R // 32, 4) * _pad(Ccols, 128)) if col else None,
+        first_dims=first_dims, tensor_offsets=tensor_offsets)
+    gin = GroupedTensor(num_tensors=num_tensors, logical_shape=(R, Ccols), dtype=tensor.dtype, rowwise_data=tensor,
+                        first_dims=first_dims, tensor_offsets=tensor_offsets)
+    wi, wo = gin.wrap(), out.wrap()
+    wn = wrap_plain(noop_flag) if noop_flag is not None else None
+    cfg = QuantizationConfig(False, 0.0, wn)
+    try:
+        api.nvte_group_quantize(wi.handle, wo.handle, cfg.handle, current_stream_ptr())
     finally:
         wi.destroy(); wo.destroy()
         if wn is not None:

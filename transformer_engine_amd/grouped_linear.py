@@ -18,19 +18,23 @@ import torch
 
 from .grouped import (GroupedTensor, general_grouped_gemm_for_grouped_tensor, group_quantize,
                       splits_to_offsets)
-from .recipe import Float8CurrentScaling, get_fp8_te_dtype
-from .tensor import Float8CurrentScalingQuantizer
+from .recipe import Float8CurrentScaling, MXFP8BlockScaling, get_fp8_te_dtype
+from .tensor import Float8CurrentScalingQuantizer, MXFP8Quantizer
 
 
 class GroupedLinearFP8State:
-    def __init__(self, recipe: Float8CurrentScaling, num_gemms: int, device=None):
-        if not isinstance(recipe, Float8CurrentScaling):
-            raise NotImplementedError("the grouped path implements FP8 per-tensor current scaling")
+    def __init__(self, recipe, num_gemms: int, device=None):
         self.recipe, self.num_gemms = recipe, num_gemms
         self.device = device or torch.device("cuda")
         f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
-        mk = lambda dt: Float8CurrentScalingQuantizer(dt, self.device, force_pow_2_scales=recipe.use_power_2_scales,
-                                                      amax_epsilon=recipe.amax_epsilon)
+        if isinstance(recipe, Float8CurrentScaling):
+            mk = lambda dt: Float8CurrentScalingQuantizer(dt, self.device, force_pow_2_scales=recipe.use_power_2_scales,
+                                                          amax_epsilon=recipe.amax_epsilon)
+        elif isinstance(recipe, MXFP8BlockScaling):
+            # member rows (m_splits) must be multiples of 128; columnwise copies per member, transposed (amd_ext.h)
+            mk = lambda dt: MXFP8Quantizer(dt, columnwise_transposed=True)
+        else:
+            raise NotImplementedError("the grouped path implements FP8 current scaling and MXFP8")
         self.q_input, self.q_weight, self.q_grad = mk(f), mk(f), mk(b)
         self.weight_cache: Optional[GroupedTensor] = None
 
