@@ -36,7 +36,11 @@ void nvte_rmsnorm_bwd(const NVTETensor dz, const NVTETensor x, const NVTETensor 
 void nvte_rmsnorm_bwd_add(const NVTETensor dz, const NVTETensor x, const NVTETensor add, const NVTETensor rsigma,
                           const NVTETensor gamma, NVTETensor dx, NVTETensor dgamma, NVTETensor workspace,
                           const int multiprocessorCount, const bool zero_centered_gamma, hipStream_t stream);
-/* ref normalization.h:170-186.  There is one backend here; the switches are accepted and ignored. */
+/* ref normalization.h:170-186.  There is one backend here, so the cuDNN switches pick no other kernels.
+ * As in the reference (normalization/common.cpp:226: only its cuDNN backend honours it), a zero-centered
+ * gamma is formed as (gamma + 1) rounded to the WEIGHT dtype when both
+ * nvte_enable_zero_centered_gamma_in_weight_dtype(true) and the cuDNN switch of that pass are on;
+ * otherwise gamma + 1 is formed in fp32. */
 void nvte_enable_cudnn_norm_fwd(bool enable);
 void nvte_enable_cudnn_norm_bwd(bool enable);
 void nvte_enable_zero_centered_gamma_in_weight_dtype(bool enable);

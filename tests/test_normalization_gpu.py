@@ -157,3 +157,49 @@ def test_norm_fwd_mixed_dtypes_take_the_general_kernel():
     assert np.allclose(rs.cpu().numpy(), rrs, rtol=5e-5, atol=1e-6)
     ref_ln, _, _, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g.float()), to_oracle_input(b.float()), 1e-5)
     assert np.allclose(out_g32.float().cpu().numpy(), ref_ln, rtol=8e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["ln", "rms"])
+@pytest.mark.parametrize("N,H", [(71, 229), (256, 4096)])
+def test_zero_centered_gamma_in_weight_dtype_switch(N, H, kind):
+    """ref tests/cpp/operator/test_normalization.h:63-93 (compute_gamma): with the cuDNN backend AND
+    nvte_enable_zero_centered_gamma_in_weight_dtype(true) the effective gamma is (gamma + 1) rounded to
+    the weight dtype; with either switch off it is gamma + 1 in fp32.  The oracle is fed the pre-rounded
+    gamma.  fp32 output so the difference between the two roundings is far above the tolerance."""
+    from transformer_engine_amd._lib import api
+    x = randn_input((N, H), torch.bfloat16, 31)
+    g = (randn_input((H,), torch.bfloat16, 32) * 0.003).contiguous()      # 1 + g is NOT a bf16 number
+    b = (randn_input((H,), torch.bfloat16, 33) * 0.25).contiguous()
+    dz = randn_input((N, H), torch.bfloat16, 34)
+    g_rounded = (g.float() + 1.0).to(torch.bfloat16)
+
+    def run():
+        if kind == "ln":
+            out, mu, rs = layernorm_fwd(x, g, b, 1e-5, zero_centered_gamma=True, out_dtype=torch.float32)
+            dx, dg, db = layernorm_bwd(dz, x, mu, rs, g, zero_centered_gamma=True)
+        else:
+            out, mu, rs = rmsnorm_fwd(x, g, 1e-5, zero_centered_gamma=True, out_dtype=torch.float32)
+            dx, dg = rmsnorm_bwd(dz, x, rs, g, zero_centered_gamma=True)
+        torch.cuda.synchronize()
+        return out.float().cpu().numpy(), dx.float().cpu().numpy(), mu, rs
+
+    try:
+        api.nvte_enable_zero_centered_gamma_in_weight_dtype(True)
+        plain_out, plain_dx, _, _ = run()                       # cuDNN switches off: fp32 gamma + 1
+        api.nvte_enable_cudnn_norm_fwd(True)
+        api.nvte_enable_cudnn_norm_bwd(True)
+        w_out, w_dx, mu, rs = run()
+    finally:
+        api.nvte_enable_zero_centered_gamma_in_weight_dtype(False)
+        api.nvte_enable_cudnn_norm_fwd(False)
+        api.nvte_enable_cudnn_norm_bwd(False)
+    beta = to_oracle_input(b) if kind == "ln" else None
+    ref_w, _, _, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g_rounded), beta, 1e-5)
+    ref_p, _, _, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g), beta, 1e-5, zero_centered_gamma=True)
+    assert np.allclose(w_out, ref_w, rtol=1e-5, atol=1e-5)
+    assert np.allclose(plain_out, ref_p, rtol=1e-5, atol=1e-5)
+    assert not np.allclose(w_out, plain_out, rtol=1e-4, atol=1e-4)          # the switch changes the numbers
+    mu_np = mu.cpu().numpy() if kind == "ln" else None
+    rdx_w, _, _ = oracle.norm_backward(to_oracle_input(dz), to_oracle_input(x), mu_np, rs.cpu().numpy(),
+                                       to_oracle_input(g_rounded))
+    assert np.allclose(w_dx, rdx_w, rtol=8e-3, atol=5e-4)

@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <cstring>
 
+#include <atomic>
+
 #include "common.h"
 #include "device_utils.h"
 #include "transformer_engine/normalization.h"
@@ -69,6 +71,16 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[4][2
   phase ^= 1u;
 }
 
+// gamma as the kernels use it.  zc: 0 = as stored, 1 = gamma + 1 in fp32 (the reference's own kernels),
+// 2 = gamma + 1 rounded to the weight dtype (its cuDNN backend with
+// nvte_enable_zero_centered_gamma_in_weight_dtype, ref tests/cpp/operator/test_normalization.h:63-93)
+__device__ __forceinline__ float gamma_eff(const void *g, size_t i, int dtype, int zc) {
+  float v = load1(g, i, dtype);
+  if (zc) v += 1.f;
+  if (zc == 2) v = round_to(v, dtype);
+  return v;
+}
+
 struct NormFwdArgs {
   const void *x, *gamma, *beta;
   void *z;
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
     const unsigned c = (v * 256 + tid) * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      g[v][k] = c < a.cols ? load1(a.gamma, c + k, a.w_dtype) + (a.zero_centered ? 1.f : 0.f) : 0.f;
+      g[v][k] = c < a.cols ? gamma_eff(a.gamma, c + k, a.w_dtype, a.zero_centered) : 0.f;
       b[v][k] = (LN && c < a.cols) ? load1(a.beta, c + k, a.w_dtype) : 0.f;
     }
   }
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256) void norm_fwd_general_kernel(const NormFwdArgs
       a.rs[row] = rs;
     }
     for (unsigned c = tid; c < a.cols; c += 256) {
-      const float gm = load1(a.gamma, c, a.w_dtype) + (a.zero_centered ? 1.f : 0.f);
+      const float gm = gamma_eff(a.gamma, c, a.w_dtype, a.zero_centered);
       float t = (load1(a.x, base + c, a.x_dtype) - mean) * rs * gm + (LN ? load1(a.beta, c, a.w_dtype) : 0.f);
       if (fp8_out) {
         amax = fmaxf(amax, __builtin_fabsf(t));
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
     const unsigned c = (v * 256 + tid) * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      g[v][k] = c < a.cols ? load1(a.gamma, c + k, a.w_dtype) + (a.zero_centered ? 1.f : 0.f) : 0.f;
+      g[v][k] = c < a.cols ? gamma_eff(a.gamma, c + k, a.w_dtype, a.zero_centered) : 0.f;
       dg[v][k] = 0.f;
       db[v][k] = 0.f;
     }
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256) void norm_bwd_general_kernel(const NormBwdArgs
     const float mean = LN ? a.mu[row] : 0.f, rs = a.rs[row];
     float sdy = 0.f, sdyy = 0.f;
     for (unsigned c = tid; c < a.cols; c += 256) {
-      const float gm = load1(a.gamma, c, a.w_dtype) + (a.zero_centered ? 1.f : 0.f);
+      const float gm = gamma_eff(a.gamma, c, a.w_dtype, a.zero_centered);
       const float y = (load1(a.x, base + c, a.x_dtype) - mean) * rs;
       const float dz = load1(a.dz, base + c, a.w_dtype);
       const float dy = gm * dz;
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256) void norm_bwd_general_kernel(const NormBwdArgs
     block_sum2(sdy, sdyy, red, phase);
     const float mdy = sdy * rn, mdyy = sdyy * rn;
     for (unsigned c = tid; c < a.cols; c += 256) {
-      const float gm = load1(a.gamma, c, a.w_dtype) + (a.zero_centered ? 1.f : 0.f);
+      const float gm = gamma_eff(a.gamma, c, a.w_dtype, a.zero_centered);
       const float y = (load1(a.x, base + c, a.x_dtype) - mean) * rs;
       const float dy = gm * load1(a.dz, base + c, a.w_dtype);
       const float ad = a.add ? load1(a.add, base + c, a.w_dtype) : 0.f;
@@ -459,6 +471,8 @@ void launch_bwd(const NormBwdArgs &args, unsigned nblocks, bool vec, hipStream_t
 }
 
 // Forward entry shared by both norms (ref ln_api.cpp:24-110, rmsnorm_api.cpp:24-110).
+std::atomic<bool> g_cudnn_fwd{false}, g_cudnn_bwd{false}, g_zc_in_wdtype{false};
+
 void norm_fwd(bool is_ln, const Tensor &x, const Tensor &gamma, const Tensor *beta, float epsilon, Tensor *z,
               Tensor *mu, Tensor *rsigma, Tensor *workspace, bool zero_centered_gamma, hipStream_t stream) {
   if (is_fp8(z->data.dtype) && !is_tensor_scaling(z->scaling_mode) && !is_mxfp8(z->scaling_mode)) {
@@ -529,7 +543,7 @@ void norm_fwd(bool is_ln, const Tensor &x, const Tensor &gamma, const Tensor *be
   a.eps = epsilon;
   a.x_dtype = x.data.dtype;
   a.w_dtype = gamma.data.dtype;
-  a.zero_centered = zero_centered_gamma ? 1 : 0;
+  a.zero_centered = zero_centered_gamma ? ((g_zc_in_wdtype.load() && g_cudnn_fwd.load()) ? 2 : 1) : 0;
   if (mx) {
     a.z = workspace->data.ptr;
     a.z_dtype = x.data.dtype;
@@ -627,7 +641,7 @@ void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, c
   a.cols = static_cast<unsigned>(cols);
   a.x_dtype = x.data.dtype;
   a.w_dtype = gamma.data.dtype;
-  a.zero_centered = zero_centered_gamma ? 1 : 0;
+  a.zero_centered = zero_centered_gamma ? ((g_zc_in_wdtype.load() && g_cudnn_bwd.load()) ? 2 : 1) : 0;
   const bool vec = cols % 8 == 0 && cols <= 8192 && aligned16(a.x) && aligned16(a.dz) && aligned16(a.dx) &&
                    (!a.add || aligned16(a.add));
   if (is_ln) launch_bwd<true>(a, nblocks, vec, stream); else launch_bwd<false>(a, nblocks, vec, stream);
@@ -697,8 +711,13 @@ void nvte_rmsnorm_bwd_add(const NVTETensor dz, const NVTETensor x, const NVTETen
   });
 }
 
-void nvte_enable_cudnn_norm_fwd(bool) {}
-void nvte_enable_cudnn_norm_bwd(bool) {}
-void nvte_enable_zero_centered_gamma_in_weight_dtype(bool) {}
+// ref common/normalization/common.cpp:567-583.  There is one backend here, so the two cuDNN switches
+// select no other kernels; they are remembered because the reference applies the weight-dtype rounding
+// of a zero-centered gamma only on its cuDNN backend (normalization/common.cpp:226,
+// tests/cpp/operator/test_normalization.h:67-69): gamma + 1 is rounded to the weight dtype exactly when
+// the caller enabled BOTH that backend for the pass and this switch.
+void nvte_enable_cudnn_norm_fwd(bool enable) { g_cudnn_fwd.store(enable); }
+void nvte_enable_cudnn_norm_bwd(bool enable) { g_cudnn_bwd.store(enable); }
+void nvte_enable_zero_centered_gamma_in_weight_dtype(bool enable) { g_zc_in_wdtype.store(enable); }
 
 }  // extern "C"
