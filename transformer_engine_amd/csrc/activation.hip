@@ -737,7 +737,7 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
     if (out.has_data()) NVTE_REQUIRE_DATA(out.data, "output");
     if (out.has_columnwise_data()) NVTE_REQUIRE_DATA(out.columnwise_data, "column-wise output");
     (void)device_info();
-    if (a.amax) NVTE_CHECK_HIP(hipMemsetAsync(a.amax, 0, sizeof(float), stream));
+    if (a.amax) zero_async(a.amax, sizeof(float), stream);
     const size_t slabs = ceil_div(rows, kSlab);
     const bool whole = rows % kTile == 0 && H % kTile == 0 && aligned16(a.in) && (!a.grad || aligned16(a.grad)) &&
                        (!a.out_c || aligned16(a.out_c)) && (!a.mx_col || aligned16(a.mx_col)) &&
@@ -750,7 +750,7 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
       if (odt == kNVTEFloat8E4M3) launch_tile_by_input<kOutMXE4M3>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
       else launch_tile_by_input<kOutMXE5M2>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
     } else {
-      if (dbias) NVTE_CHECK_HIP(hipMemsetAsync(a.dbias_part, 0, slabs * H * sizeof(float), stream));
+      if (dbias) zero_async(a.dbias_part, slabs * H * sizeof(float), stream);
       const size_t tiles = ceil_div(rows, 32) * ceil_div(out_cols, 32);
       NVTE_CHECK(tiles < (1ull << 31), "tensor too large");
       if (odt == kNVTEFloat8E4M3)
@@ -818,7 +818,7 @@ void fused_act_launch(int mode, int act, const Tensor *grad, const Tensor &in, T
     else if (odt == kNVTEFloat8E5M2) launch_tile_by_input<kOutE5M2>(mode, a, dbias != nullptr, grid, stream);
     else launch_tile_by_input<kOutHP>(mode, a, dbias != nullptr, grid, stream);
   } else {
-    if (dbias) NVTE_CHECK_HIP(hipMemsetAsync(a.dbias_part, 0, slabs * H * sizeof(float), stream));
+    if (dbias) zero_async(a.dbias_part, slabs * H * sizeof(float), stream);
     const unsigned grid = static_cast<unsigned>(std::min<size_t>(ceil_div(rows * H, 256), static_cast<size_t>(device_info().num_cus) * 16));
     hipLaunchKernelGGL(fused_act_general_kernel, dim3(grid), dim3(256), 0, stream, a, mode);
   }

@@ -207,6 +207,13 @@ void check_scale_shapes(const Tensor &t, const char *name);
 void check_input(const Tensor &t, const char *name, bool check_scale_shapes_too = true);
 void check_output(const Tensor &t, const char *name, bool allow_empty = false);
 
+// Stream-ordered fill by a kernel of this library (tensor_api.cpp).  Used instead of hipMemsetAsync
+// wherever a launch may be captured into a HIP graph: a memset node followed by a kernel node with a
+// large argument block was seen to write a 16-byte pattern of that kernel's arguments instead of the
+// fill value from the second replay on (ROCm 7.2, gfx950; scratch/dbg_splitk_graph.py).
+void fill_async(void *ptr, int value, size_t bytes, hipStream_t stream);
+inline void zero_async(void *ptr, size_t bytes, hipStream_t stream) { fill_async(ptr, 0, bytes, stream); }
+
 // ---------------------------------------------------------------- grouped tensor descriptor
 // ref common/common.h:452-600.  All payload buffers are flat 1-D; member i is the
 // [first_i, last_i] matrix at element offset tensor_offsets[i] (or i * M * N when uniform).

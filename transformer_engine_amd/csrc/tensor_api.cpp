@@ -12,6 +12,10 @@
 #include <memory>
 #include <mutex>
 
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
 #include "common.h"
 #include "transformer_engine/amd_ext.h"
 #include "transformer_engine/gemm.h"
@@ -322,6 +326,36 @@ const DeviceInfo &device_info() {
 
 }  // namespace te
 
+namespace te {
+namespace {
+// 16 bytes per thread where the range allows it, single bytes at the ragged ends
+__global__ __launch_bounds__(256) void fill_bytes_kernel(uint8_t *p, uint32_t word, size_t head, size_t vecs, size_t bytes) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t step = static_cast<size_t>(gridDim.x) * blockDim.x;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t v = {word, word, word, word};
+  for (size_t k = i; k < vecs; k += step) reinterpret_cast<u32x4_t *>(p + head)[k] = v;
+  const size_t tail0 = head + vecs * 16;
+  for (size_t k = i; k < head; k += step) p[k] = static_cast<uint8_t>(word);
+  for (size_t k = tail0 + i; k < bytes; k += step) p[k] = static_cast<uint8_t>(word);
+}
+}  // namespace
+
+void fill_async(void *ptr, int value, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return;
+  NVTE_CHECK(ptr != nullptr, "fill of a null pointer");
+  const uint32_t b = static_cast<uint32_t>(value) & 0xFFu;
+  const uint32_t word = b | (b << 8) | (b << 16) | (b << 24);
+  const size_t mis = reinterpret_cast<uintptr_t>(ptr) & 15u;
+  const size_t head = std::min(bytes, mis ? 16 - mis : 0);
+  const size_t vecs = (bytes - head) / 16;
+  const size_t work = std::max<size_t>(vecs, 16);
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>((work + 255) / 256, 4096));
+  hipLaunchKernelGGL(fill_bytes_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint8_t *>(ptr), word, head, vecs, bytes);
+  NVTE_CHECK_HIP(hipGetLastError());
+}
+}  // namespace te
+
 using namespace te;
 
 // =================================================================== C ABI
@@ -602,9 +636,9 @@ void nvte_zero_tensor(const NVTETensor tensor, hipStream_t stream) {
   api_guard("nvte_zero_tensor", [&] {
     Tensor &t = *lookup_checked(tensor);
     if (t.data.ptr != nullptr && t.data.bytes() > 0)
-      NVTE_CHECK_HIP(hipMemsetAsync(t.data.ptr, 0, t.data.bytes(), stream));
+      zero_async(t.data.ptr, t.data.bytes(), stream);
     if (t.amax.ptr != nullptr && t.amax.bytes() > 0)
-      NVTE_CHECK_HIP(hipMemsetAsync(t.amax.ptr, 0, t.amax.bytes(), stream));
+      zero_async(t.amax.ptr, t.amax.bytes(), stream);
   });
 }
 
@@ -612,7 +646,7 @@ void nvte_memset(void *ptr, int value, size_t size_in_bytes, hipStream_t stream)
   api_guard("nvte_memset", [&] {
     if (size_in_bytes == 0) return;
     NVTE_CHECK(ptr != nullptr, "Pointer for memset must be allocated.");
-    NVTE_CHECK_HIP(hipMemsetAsync(ptr, value, size_in_bytes, stream));
+    fill_async(ptr, value, size_in_bytes, stream);
   });
 }
 
