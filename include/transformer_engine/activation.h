@@ -58,6 +58,23 @@ void nvte_clamped_dswiglu(const NVTETensor grad, const NVTETensor input, NVTETen
 void nvte_clamped_dswiglu_v2(const NVTETensor grad, const NVTETensor input, NVTETensor output, float limit,
                              float alpha, float glu_linear_offset, hipStream_t stream);
 
+/* Grouped forms (ref activation.h:65,86,107,128,149): the unary activation of every member of a grouped
+ * tensor, cast as output's scaling mode asks - FP8 per-tensor scaling with output.scale[i] per member (amax /
+ * scale_inv untouched, as nvte_group_quantize) or MXFP8 (rows of every member and the last dim multiples of
+ * 128).  Member shapes are read on the device.  Same-shape and varying-first-dim groups. */
+void nvte_group_gelu(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+void nvte_group_silu(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+void nvte_group_relu(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+void nvte_group_qgelu(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+void nvte_group_srelu(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+/* ref activation.h:173,198,223,248,273 (output is declared NVTETensor there; it is a grouped handle):
+ * output = cast(grad * act'(input)) per member. */
+void nvte_group_dgelu(const NVTEGroupedTensor grad, const NVTEGroupedTensor input, NVTETensor output, hipStream_t stream);
+void nvte_group_dsilu(const NVTEGroupedTensor grad, const NVTEGroupedTensor input, NVTETensor output, hipStream_t stream);
+void nvte_group_drelu(const NVTEGroupedTensor grad, const NVTEGroupedTensor input, NVTETensor output, hipStream_t stream);
+void nvte_group_dqgelu(const NVTEGroupedTensor grad, const NVTEGroupedTensor input, NVTETensor output, hipStream_t stream);
+void nvte_group_dsrelu(const NVTEGroupedTensor grad, const NVTEGroupedTensor input, NVTETensor output, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,28 @@ void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
  * compact or GEMM-swizzled scales per output's with_gemm_swizzled_scales. */
 void nvte_group_quantize(const NVTEGroupedTensor input, NVTEGroupedTensor output,
                          const NVTEQuantizationConfig quant_config, hipStream_t stream);
+/* ref cast.h:167.  Grouped cast + dbias: output as nvte_group_quantize (FP8 per-tensor scaling with
+ * output.scale[i] per member, or MXFP8), dbias [num_tensors, last] = column sums of every member, in the
+ * input dtype.  Same-shape and varying-first-dim groups (the reference: "not yet supported for grouped tensors
+ * with a varying last dimension").  Two-call protocol: an empty workspace only receives its shape. */
+void nvte_group_quantize_dbias(const NVTEGroupedTensor input, NVTEGroupedTensor output, NVTEGroupedTensor dbias,
+                               NVTETensor workspace, const NVTEQuantizationConfig quant_config, hipStream_t stream);
+/* ref cast.h:214,262,310,358,406.  output = cast(input * dact(act_input)), dbias = its column sums per member. */
+void nvte_group_quantize_dbias_dgelu(const NVTEGroupedTensor input, const NVTEGroupedTensor act_input,
+                                     NVTEGroupedTensor output, NVTEGroupedTensor dbias, NVTETensor workspace,
+                                     hipStream_t stream);
+void nvte_group_quantize_dbias_dsilu(const NVTEGroupedTensor input, const NVTEGroupedTensor act_input,
+                                     NVTEGroupedTensor output, NVTEGroupedTensor dbias, NVTETensor workspace,
+                                     hipStream_t stream);
+void nvte_group_quantize_dbias_drelu(const NVTEGroupedTensor input, const NVTEGroupedTensor act_input,
+                                     NVTEGroupedTensor output, NVTEGroupedTensor dbias, NVTETensor workspace,
+                                     hipStream_t stream);
+void nvte_group_quantize_dbias_dqgelu(const NVTEGroupedTensor input, const NVTEGroupedTensor act_input,
+                                      NVTEGroupedTensor output, NVTEGroupedTensor dbias, NVTETensor workspace,
+                                      hipStream_t stream);
+void nvte_group_quantize_dbias_dsrelu(const NVTEGroupedTensor input, const NVTEGroupedTensor act_input,
+                                      NVTEGroupedTensor output, NVTEGroupedTensor dbias, NVTETensor workspace,
+                                      hipStream_t stream);
 /* ref cast.h:429 */
 void nvte_group_dequantize(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
 

@@ -1,4 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout -k 5 200 python -u -m pytest tests/test_graph_gpu.py tests/test_gemm_gpu.py -x -q --timeout 60 --timeout-method thread > gpurun_out/graph_tests.log 2>&1
-tail -15 gpurun_out/graph_tests.log
+timeout -k 5 300 python -u -m pytest tests/test_grouped_activation_gpu.py -x -q --timeout 60 --timeout-method thread > gpurun_out/gact.log 2>&1
+rc=$?
+tail -40 gpurun_out/gact.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 5 300 python -u -m pytest tests/test_activation_gpu.py tests/test_grouped_gpu.py tests/test_grouped_mxfp8_gpu.py -x -q --timeout 60 --timeout-method thread 2>&1 | tail -4

@@ -82,6 +82,22 @@ _SIGS = {
     "nvte_amd_version": (C.c_char_p, []),
     "nvte_amd_set_columnwise_transposed": (_V, [_P, _I]),
     "nvte_amd_set_grouped_columnwise_transposed": (_V, [_P, _I]),
+    "nvte_group_gelu": (_V, [_P, _P, _P]),
+    "nvte_group_dgelu": (_V, [_P, _P, _P, _P]),
+    "nvte_group_quantize_dbias_dgelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_group_silu": (_V, [_P, _P, _P]),
+    "nvte_group_dsilu": (_V, [_P, _P, _P, _P]),
+    "nvte_group_quantize_dbias_dsilu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_group_relu": (_V, [_P, _P, _P]),
+    "nvte_group_drelu": (_V, [_P, _P, _P, _P]),
+    "nvte_group_quantize_dbias_drelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_group_qgelu": (_V, [_P, _P, _P]),
+    "nvte_group_dqgelu": (_V, [_P, _P, _P, _P]),
+    "nvte_group_quantize_dbias_dqgelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_group_srelu": (_V, [_P, _P, _P]),
+    "nvte_group_dsrelu": (_V, [_P, _P, _P, _P]),
+    "nvte_group_quantize_dbias_dsrelu": (_V, [_P, _P, _P, _P, _P, _P]),
+    "nvte_group_quantize_dbias": (_V, [_P, _P, _P, _P, _P, _P]),
     "nvte_amd_get_grouped_columnwise_transposed": (_I, [_P]),
     "nvte_amd_get_columnwise_transposed": (_I, [_P]),
     "nvte_amd_delayed_scaling_after_reduction": (_V, [_P, C.POINTER(_P), C.POINTER(_P), _SZ, C.c_char_p, _I, _F, _P]),

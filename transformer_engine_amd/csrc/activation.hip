@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "device_utils.h"
+#include "group_lookup.h"
 #include "transformer_engine/activation.h"
 #include "transformer_engine/cast.h"
 #include "transformer_engine/transpose.h"
@@ -122,6 +123,11 @@ struct FusedArgs {
   int swz, tcol;                // GEMM-swizzled scales; column-wise payload stored transposed (amd_ext.h)
   // clamped SwiGLU (ref math.h:80-98, vectorized_pointwise.h:436-438,543-546)
   float limit, alpha, glu_offset;
+  // grouped launch (nvte_group_*; grp.num_tensors != 0): the buffers above are the GROUP's flat buffers, `rows`
+  // the logical first dim of the group, `scale` one entry per member; every workgroup looks its member up
+  // on the device and re-bases the pointers (unary / d-act modes, uniform last dim)
+  GroupShapes grp;
+  unsigned pad_cols;  // grouped MXFP8, transposed column-wise scales: pad128(cols), rows of a member's scale matrix
 };
 
 // compact -> GEMM-swizzled scale index (ref common/cast/mxfp8/swizzle.cuh:30-41; twin of mxfp8.hip)
@@ -310,7 +316,7 @@ __device__ __forceinline__ float round_to_input_type(float v) {
 // workgroup around seven inlined bodies) ends up as a branch tree PER ELEMENT after LLVM merges the
 // bodies back together - measured 103 us instead of 76 us for relu -> FP8 + transpose.
 template <typename IT, int OK, int MODE, int ACT, bool DBIAS>
-__global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) {
+__global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a_in) {
   constexpr bool FP8 = OK == kOutE4M3 || OK == kOutE5M2;       // per-tensor scaling
   constexpr bool MXO = OK == kOutMXE4M3 || OK == kOutMXE5M2;   // MXFP8 block scaling (whole tiles only)
   constexpr int NOUT = MODE == kGatedBwd ? 2 : 1;
@@ -320,8 +326,40 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a) 
   __shared__ float colpart[DBIAS ? 16 : 1][kTile];
   __shared__ float red[4];
   const unsigned t = threadIdx.x, cg = t & 15u, rg = t >> 4;
+  FusedArgs a = a_in;
   const unsigned tiles_c = (a.cols + kTile - 1) / kTile;
-  const size_t tile_r = blockIdx.x / tiles_c, tile_col = blockIdx.x % tiles_c;
+  size_t tile_r = blockIdx.x / tiles_c, tile_col = blockIdx.x % tiles_c;
+  if constexpr (!GATED) {
+    if (a.grp.num_tensors != 0) {
+      // grouped: which member, which of its tiles; then everything below sees ONE member
+      unsigned mem, lt;
+      if (!locate_tile(a.grp, blockIdx.x, mem, lt)) return;
+      const Member m = member_of(a.grp, mem);
+      const size_t off = static_cast<size_t>(m.off), row_base = off / a.cols;
+      const size_t out_esz = (FP8 || MXO) ? 1 : (a.out_dtype == kNVTEFloat32 ? 4 : 2);
+      tile_r = lt / tiles_c;
+      tile_col = lt % tiles_c;
+      a.rows = static_cast<unsigned>(m.rows);
+      a.in = static_cast<const IT *>(a.in) + off;
+      if (a.grad) a.grad = static_cast<const IT *>(a.grad) + off;
+      if (a.out_c) a.out_c = static_cast<char *>(a.out_c) + off * out_esz;
+      if (a.out_t) a.out_t += off;
+      if (a.scale) a.scale += mem;
+      a.scale_inv = nullptr;  // per-member scale_inv belongs to nvte_group_compute_scale_from_amax
+      if (a.mx_col) a.mx_col += off;
+      if (a.sc_row) a.sc_row += row_base * a.stride_r;  // the member's GLOBAL rows (compact and swizzled alike)
+      if (a.sc_col) {
+        if (a.tcol) {
+          a.sc_col += static_cast<size_t>(a.pad_cols) * (row_base / 32);
+          a.stride_c = static_cast<unsigned>((m.rows / 32 + 3) / 4 * 4);
+        } else {
+          a.sc_col += (row_base / 32) * a.stride_c;
+        }
+      }
+      // dbias slabs are numbered by the global tile row (unique for any member sizes)
+      if (a.dbias_part) a.dbias_part += (blockIdx.x / tiles_c - tile_r) * static_cast<size_t>(a.cols);
+    }
+  }
   const size_t row0 = tile_r * kTile + rg * 8, col0 = tile_col * kTile + cg * 8;
   const bool col_ok = col0 < a.cols;
   const size_t col_ld = col_ok ? col0 : 0;  // out-of-tile threads load a valid address and drop the value
@@ -641,6 +679,133 @@ void launch_tile_by_input(int mode, const FusedArgs &a, bool dbias, unsigned gri
   }
 }
 
+// ---------------------------------------------------------------- grouped forms (nvte_group_*)
+// dbias[i, c] = sum over member i's slabs of part[slab, c]; slabs are numbered by the global tile row, member
+// i's first slab is the number of tile rows of the members before it.  One workgroup per (member, 256 columns).
+__global__ __launch_bounds__(256) void group_dbias_reduce_kernel(const float *__restrict__ part, void *__restrict__ dbias,
+                                                                 int out_dtype, const GroupShapes g, unsigned cols) {
+  const unsigned mem = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  size_t first = 0;
+  for (unsigned j = 0; j < mem; ++j) first += static_cast<size_t>((member_of(g, j).rows + kTile - 1) / kTile);
+  const size_t n = static_cast<size_t>((member_of(g, mem).rows + kTile - 1) / kTile);
+  if (c >= cols) return;
+  float s = 0.f;
+  for (size_t k = 0; k < n; ++k) s += part[(first + k) * cols + c];
+  store1(dbias, static_cast<size_t>(mem) * cols + c, out_dtype, s);
+}
+
+}  // namespace
+
+// ref cast/dispatch/quantize.cuh:430-540 (group_quantize_fwd_helper / group_quantize_bwd_helper): unary
+// activation or d-activation of every member, then the cast the output's scaling mode asks for - FP8
+// per-tensor scaling with output.scale[i] per member (amax / scale_inv untouched, as nvte_group_quantize)
+// or MXFP8 - and optionally dbias[i, :] = column sums of member i.  Same-shape and varying-first-dim groups.
+void fused_act_group_launch(const char *api, int mode, int act, const GroupedTensor *grad, const GroupedTensor &in,
+                            GroupedTensor &out, GroupedTensor *dbias, Tensor *workspace,
+                            const NVTEQuantizationConfig quant_config, hipStream_t stream) {
+  (void)quant_config;
+  check_grouped_input(in, "input");
+  NVTE_CHECK(in.has_data() && is_high_precision(in.data.dtype), api, ": input must be FP32/BF16/FP16 row-wise data");
+  NVTE_CHECK(in.num_tensors == out.num_tensors, api, ": number of input and output tensors must be same");
+  NVTE_CHECK(out.all_same_last_dim() && in.all_same_last_dim(), api,
+             ": implemented for same-shape and varying-first-dimension grouped tensors");
+  const size_t R = out.logical_shape.data[0], C = out.logical_shape.data[1], T = out.num_tensors;
+  NVTE_CHECK(in.logical_shape.data[0] == R && in.logical_shape.data[1] == C, api, ": input and output shapes differ");
+  NVTE_CHECK(T <= kMaxMembers, api, ": at most ", kMaxMembers, " member tensors are supported");
+  if (grad) {
+    check_grouped_input(*grad, "grad");
+    NVTE_CHECK(grad->has_data() && grad->data.dtype == in.data.dtype, api, ": grad and input must have the same dtype");
+    NVTE_CHECK(grad->logical_shape.data[0] == R && grad->logical_shape.data[1] == C && grad->num_tensors == T, api,
+               ": grad and input shapes differ");
+  }
+  const bool mx = is_mxfp8(out.scaling_mode);
+  const size_t tile_rows = out.all_same_shape() ? T * ceil_div(R / T, kTile) : ceil_div(R, kTile) + T;
+  if (dbias) {
+    NVTE_CHECK(workspace != nullptr, api, ": dbias needs a workspace tensor");
+    if (workspace->data.ptr == nullptr) {  // ref two-call protocol (cast.h:157-158)
+      workspace->data.shape = NVTEShape{{tile_rows, C}, 2};
+      workspace->data.dtype = kNVTEFloat32;
+      return;
+    }
+    NVTE_CHECK(dbias->has_data() && dbias->data.dtype == in.data.dtype, api, ": DBias must have the same type as input.");
+    NVTE_CHECK(dbias->data.numel() == T * C, api, ": Wrong shape of DBias (expected ", T, "x", C, ")");
+    NVTE_CHECK(workspace->data.dtype == kNVTEFloat32 && workspace->data.numel() >= tile_rows * C, api,
+               ": Workspace is too small (need ", tile_rows * C, " fp32 entries)");
+  }
+  check_grouped_output(out, "output", false);
+  NVTE_CHECK(mx || (is_tensor_scaling(out.scaling_mode) && is_fp8(out.dtype())), api,
+             ": FP8 per-tensor scaling and MXFP8 grouped outputs are implemented, got ", scaling_mode_name(out.scaling_mode));
+  NVTE_CHECK(R < (1ull << 31) && C < (1ull << 31), "tensor too large");
+  if (R == 0 || C == 0) return;
+  const GroupShapes g = group_shapes_of(out);
+  if (!out.all_same_shape()) NVTE_CHECK(g.offsets && g.first_dims, api, ": varying first dims need first_dims and tensor_offsets");
+  else NVTE_CHECK(R % T == 0, api, ": first logical dimension must be divisible by num_tensors");
+
+  FusedArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = in.data.ptr;
+  a.grad = grad ? grad->data.ptr : nullptr;
+  a.dbias_part = dbias ? static_cast<float *>(workspace->data.ptr) : nullptr;
+  a.rows = static_cast<unsigned>(R);
+  a.cols = static_cast<unsigned>(C);
+  a.ld_in = a.ld_out = static_cast<unsigned>(C);
+  a.in_dtype = in.data.dtype;
+  a.out_dtype = out.dtype();
+  a.act = act;
+  a.grp = g;
+  NVTE_REQUIRE_DATA(in.data, "grouped activation input");
+  const size_t tiles = tile_rows * ceil_div(C, kTile);
+  NVTE_CHECK(tiles < (1ull << 31), "grouped tensor too large");
+  (void)device_info();
+  if (mx) {
+    NVTE_CHECK(R % 128 == 0 && C % 128 == 0, api, ": grouped MXFP8 tensors need 128-multiple dims, got ", R, "x", C);
+    if (out.all_same_shape()) NVTE_CHECK((R / T) % 128 == 0, api, ": member first dim must be a multiple of 128");
+    a.swz = out.with_gemm_swizzled_scales ? 1 : 0;
+    a.tcol = (out.has_columnwise_data() && out.columnwise_transposed) ? 1 : 0;
+    a.pad_cols = static_cast<unsigned>(round_up(C, 128));
+    if (out.has_data()) {
+      a.out_c = out.data.ptr;
+      a.sc_row = static_cast<uint8_t *>(out.scale_inv.ptr);
+      a.stride_r = static_cast<unsigned>(round_up(C / 32, 4));
+      NVTE_CHECK(a.out_c && a.sc_row && out.scale_inv.numel() >= round_up(R, 128) * a.stride_r, api,
+                 ": row-wise MXFP8 output or its scale_inv is missing / too small");
+    }
+    if (out.has_columnwise_data()) {
+      NVTE_CHECK(a.tcol || !a.swz, api, ": swizzled column-wise scales of a grouped output need the transposed layout");
+      a.mx_col = static_cast<uint8_t *>(out.columnwise_data.ptr);
+      a.sc_col = static_cast<uint8_t *>(out.columnwise_scale_inv.ptr);
+      a.stride_c = a.pad_cols;  // reference layout: [sum first / 32, pad128(cols)]
+      NVTE_CHECK(a.mx_col && a.sc_col && out.columnwise_scale_inv.numel() >= round_up(R / 32, 4) * a.pad_cols, api,
+                 ": column-wise MXFP8 output or its scale_inv is missing / too small");
+    }
+    NVTE_CHECK(aligned16(a.in) && (!a.grad || aligned16(a.grad)) && (!a.out_c || aligned16(a.out_c)) &&
+                   (!a.mx_col || aligned16(a.mx_col)) && (!a.sc_row || aligned16(a.sc_row)) && (!a.sc_col || aligned16(a.sc_col)),
+               api, ": grouped MXFP8 needs 16-byte aligned buffers");
+    if (a.out_dtype == kNVTEFloat8E4M3) launch_tile_by_input<kOutMXE4M3>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
+    else launch_tile_by_input<kOutMXE5M2>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
+  } else {
+    a.out_c = out.data.ptr;
+    a.out_t = static_cast<uint8_t *>(out.columnwise_data.ptr);
+    a.scale = static_cast<const float *>(out.scale.ptr);
+    NVTE_CHECK(a.scale != nullptr && out.scale.numel() >= T, api, ": grouped FP8 output needs one scale per member");
+    NVTE_CHECK(a.out_c || a.out_t, api, ": output has shapes but no data pointers");
+    // vector path only (members padded to 16 rows for the transposes, as nvte_group_quantize's fast path)
+    NVTE_CHECK(C % 8 == 0 && aligned16(a.in) && (!a.grad || aligned16(a.grad)) && (!a.out_c || aligned16(a.out_c)) &&
+                   (!a.out_t || aligned16(a.out_t)),
+               api, ": grouped FP8 activation needs a last dim multiple of 8 and 16-byte aligned buffers");
+    if (a.out_dtype == kNVTEFloat8E4M3) launch_tile_by_input<kOutE4M3>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
+    else launch_tile_by_input<kOutE5M2>(mode, a, dbias != nullptr, static_cast<unsigned>(tiles), stream);
+  }
+  NVTE_CHECK_HIP(hipGetLastError());
+  if (dbias) {
+    hipLaunchKernelGGL(group_dbias_reduce_kernel, dim3(static_cast<unsigned>(T), static_cast<unsigned>(ceil_div(C, 256))),
+                       dim3(256), 0, stream, a.dbias_part, dbias->data.ptr, static_cast<int>(dbias->data.dtype), g,
+                       static_cast<unsigned>(C));
+    NVTE_CHECK_HIP(hipGetLastError());
+  }
+}
+
+namespace {
 }  // namespace
 
 // mode / act: the enums above.  grad may be null (unary, gated forward); dbias + workspace are both
@@ -945,5 +1110,54 @@ TE_DGATED_CT(nvte_dswiglu_cast_transpose, kActSilu)
 TE_DGATED_CT(nvte_dreglu_cast_transpose, kActRelu)
 TE_DGATED_CT(nvte_dqgeglu_cast_transpose, kActQGelu)
 TE_DGATED_CT(nvte_dsreglu_cast_transpose, kActSRelu)
+
+// ---- grouped forms: ref activation.h:65-149 (forward), :173-275 (backward), cast.h:167-410 (dbias [+ d-act])
+#define TE_GROUP_UNARY(name, act_id)                                                                       \
+  void name(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream) {                 \
+    api_guard(#name, [&] {                                                                                 \
+      fused_act_group_launch(#name, kUnary, act_id, nullptr, *lookup_grouped_checked(input),               \
+                             *lookup_grouped_checked(output), nullptr, nullptr, nullptr, stream);          \
+    });                                                                                                    \
+  }
+#define TE_GROUP_DACT(name, act_id)                                                                        \
+  void name(const NVTEGroupedTensor grad, const NVTEGroupedTensor input, NVTETensor output, hipStream_t stream) { \
+    api_guard(#name, [&] {                                                                                 \
+      fused_act_group_launch(#name, kDAct, act_id, lookup_grouped_checked(grad), *lookup_grouped_checked(input), \
+                             *lookup_grouped_checked(output), nullptr, nullptr, nullptr, stream);          \
+    });                                                                                                    \
+  }
+#define TE_GROUP_DBIAS_DACT(name, act_id)                                                                  \
+  void name(const NVTEGroupedTensor input, const NVTEGroupedTensor act_input, NVTEGroupedTensor output,    \
+            NVTEGroupedTensor dbias, NVTETensor workspace, hipStream_t stream) {                           \
+    api_guard(#name, [&] {                                                                                 \
+      fused_act_group_launch(#name, kDAct, act_id, lookup_grouped_checked(input), *lookup_grouped_checked(act_input), \
+                             *lookup_grouped_checked(output), lookup_grouped_checked(dbias),               \
+                             lookup_checked(workspace), nullptr, stream);                                  \
+    });                                                                                                    \
+  }
+TE_GROUP_UNARY(nvte_group_gelu, kActGelu)
+TE_GROUP_UNARY(nvte_group_silu, kActSilu)
+TE_GROUP_UNARY(nvte_group_relu, kActRelu)
+TE_GROUP_UNARY(nvte_group_qgelu, kActQGelu)
+TE_GROUP_UNARY(nvte_group_srelu, kActSRelu)
+TE_GROUP_DACT(nvte_group_dgelu, kActGelu)
+TE_GROUP_DACT(nvte_group_dsilu, kActSilu)
+TE_GROUP_DACT(nvte_group_drelu, kActRelu)
+TE_GROUP_DACT(nvte_group_dqgelu, kActQGelu)
+TE_GROUP_DACT(nvte_group_dsrelu, kActSRelu)
+TE_GROUP_DBIAS_DACT(nvte_group_quantize_dbias_dgelu, kActGelu)
+TE_GROUP_DBIAS_DACT(nvte_group_quantize_dbias_dsilu, kActSilu)
+TE_GROUP_DBIAS_DACT(nvte_group_quantize_dbias_drelu, kActRelu)
+TE_GROUP_DBIAS_DACT(nvte_group_quantize_dbias_dqgelu, kActQGelu)
+TE_GROUP_DBIAS_DACT(nvte_group_quantize_dbias_dsrelu, kActSRelu)
+
+void nvte_group_quantize_dbias(const NVTEGroupedTensor input, NVTEGroupedTensor output, NVTEGroupedTensor dbias,
+                               NVTETensor workspace, const NVTEQuantizationConfig quant_config, hipStream_t stream) {
+  api_guard("nvte_group_quantize_dbias", [&] {
+    fused_act_group_launch("nvte_group_quantize_dbias", kUnary, kActNone, nullptr, *lookup_grouped_checked(input),
+                           *lookup_grouped_checked(output), lookup_grouped_checked(dbias), lookup_checked(workspace),
+                           quant_config, stream);
+  });
+}
 
 }  // extern "C"

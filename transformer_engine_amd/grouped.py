@@ -230,6 +230,90 @@ def _group_quantize_mxfp8(tensor, quantizer: MXFP8Quantizer, num_tensors, first_
     return out
 
 
+def _alloc_grouped_out(tensor, quantizer, num_tensors, first_dims, tensor_offsets):
+    """Empty grouped output for `quantizer`: MXFP8, or FP8 per-tensor scaling with the quantizer's per-member
+    scale vector (a delayed-scaling Float8Quantizer whose scale has num_tensors entries)."""
+    R, Ccols = tensor.shape
+    dev = tensor.device
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    row, col = quantizer.rowwise_usage, quantizer.columnwise_usage
+    if isinstance(quantizer, MXFP8Quantizer):
+        if R % 128 or Ccols % 128:
+            raise ValueError(f"grouped MXFP8 needs 128-multiple dims, got {R}x{Ccols}")
+        return GroupedTensor(
+            num_tensors=num_tensors, logical_shape=(R, Ccols), dtype=tensor.dtype, fp8_dtype=quantizer.dtype,
+            scaling_mode=_lib.NVTE_MXFP8_1D_SCALING, columnwise_transposed=col and quantizer.columnwise_transposed,
+            with_gemm_swizzled_scales=quantizer.optimize_for_gemm,
+            rowwise_data=u8(R * Ccols) if row else None, columnwise_data=u8(R * Ccols) if col else None,
+            scale_inv=u8(_pad(R, 128) * _pad(Ccols // 32, 4)) if row else None,
+            columnwise_scale_inv=u8(_pad(R // 32, 4) * _pad(Ccols, 128)) if col else None,
+            first_dims=first_dims, tensor_offsets=tensor_offsets)
+    if isinstance(quantizer, Float8Quantizer) and not isinstance(quantizer, Float8CurrentScalingQuantizer):
+        if quantizer.scale.numel() != num_tensors:
+            raise ValueError("grouped delayed scaling needs one scale per member tensor")
+        sinv = (1.0 / quantizer.scale).to(torch.float32)
+        return GroupedTensor(
+            num_tensors=num_tensors, logical_shape=(R, Ccols), dtype=tensor.dtype, fp8_dtype=quantizer.dtype,
+            rowwise_data=u8(R * Ccols) if row else None, columnwise_data=u8(R * Ccols) if col else None,
+            scale=quantizer.scale.to(torch.float32).contiguous(), amax=torch.zeros(num_tensors, dtype=torch.float32, device=dev),
+            scale_inv=sinv if row else None, columnwise_scale_inv=sinv if col else None,
+            first_dims=first_dims, tensor_offsets=tensor_offsets)
+    raise NotImplementedError(f"grouped fused activation output for {type(quantizer).__name__} is not implemented "
+                              "(MXFP8, or FP8 per-tensor scaling with per-member scales)")
+
+
+def group_activation(name: Optional[str], x: torch.Tensor, quantizer, num_tensors: int,
+                     first_dims: Optional[torch.Tensor] = None, *, grad: Optional[torch.Tensor] = None,
+                     with_dbias: bool = False):
+    """Grouped activation + cast in ONE launch over all members (ref activation.h:65-275, cast.h:167-410):
+      grad is None, name given  -> nvte_group_<name>            out_i = cast(act(x_i))
+      grad given                -> nvte_group_d<name>           out_i = cast(grad_i * act'(x_i))
+      with_dbias                -> nvte_group_quantize_dbias[_d<name>]  (+ dbias [num_tensors, cols])
+    Returns the grouped output, or (output, dbias)."""
+    if name is not None and name not in ("gelu", "silu", "relu", "qgelu", "srelu"):
+        raise ValueError(f"unknown grouped activation {name}")
+    if x.dim() != 2:
+        raise ValueError("Tensor must be 2D")
+    x = x if x.is_contiguous() else x.contiguous()
+    R, Ccols = x.shape
+    offs = splits_to_offsets(first_dims, Ccols) if first_dims is not None else None
+    out = _alloc_grouped_out(x, quantizer, num_tensors, first_dims, offs)
+    hp = lambda t: GroupedTensor(num_tensors=num_tensors, logical_shape=(R, Ccols), dtype=t.dtype, rowwise_data=t,
+                                 first_dims=first_dims, tensor_offsets=offs)
+    wx, wo = hp(x).wrap(), out.wrap()
+    tmp, gtmp = [], [wx, wo]
+    stream = current_stream_ptr()
+    dbias = None
+    try:
+        if grad is not None:
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            wg = hp(grad).wrap(); gtmp.append(wg)
+        if with_dbias:
+            dbias = torch.empty(num_tensors, Ccols, dtype=x.dtype, device=x.device)
+            wdb = GroupedTensor(num_tensors=num_tensors, logical_shape=(num_tensors, Ccols), dtype=x.dtype,
+                                rowwise_data=dbias).wrap()
+            gtmp.append(wdb)
+            wws = TensorWrapper(); tmp.append(wws)
+            call = (lambda ws: api.nvte_group_quantize_dbias(wx.handle, wo.handle, wdb.handle, ws, None, stream)) \
+                if grad is None else \
+                (lambda ws: getattr(api, f"nvte_group_quantize_dbias_d{name}")(wg.handle, wx.handle, wo.handle, wdb.handle, ws, stream))
+            if grad is None and name is not None:
+                raise ValueError("dbias of a forward activation does not exist in the reference API")
+            call(wws.handle)                       # first call: workspace shape only
+            shape = wws.shape()
+            work = torch.empty(shape, dtype=torch.float32, device=x.device)
+            wws2 = wrap_plain(work); tmp.append(wws2)
+            call(wws2.handle)
+        elif grad is not None:
+            getattr(api, f"nvte_group_d{name}")(wg.handle, wx.handle, wo.handle, stream)
+        else:
+            getattr(api, f"nvte_group_{name}")(wx.handle, wo.handle, stream)
+    finally:
+        for w in tmp + gtmp:
+            w.destroy()
+    return (out, dbias) if with_dbias else out
+
+
 _SETUP_WS = {}
 _ONES = {}
 _ZEROS = {}
