@@ -416,17 +416,21 @@ def main():
         def instrumented_step():
             qi.set_usage(rowwise=True, columnwise=True)
             with rec("cast_transpose_x"):
-                sx8 = qi(x)
+                qi.update_quantized(x, ox)
+            sx8 = ox
+            # outputs preallocated (y / dx / dw above): an allocator call between the two events of a pair would be
+            # charged to the kernel (seen: one 67 MB torch.empty stalling a dgrad pair to 0.9 ms)
             with rec("gemm_fprop"):
-                general_gemm(st.weight_cache, sx8, out_dtype=torch.bfloat16, layout="TN")
+                general_gemm(st.weight_cache, sx8, layout="TN", out=y)
             st.update_fwd()
             qg.set_usage(rowwise=True, columnwise=True)
             with rec("cast_transpose_dy"):
-                sdy8 = qg(dy)
+                qg.update_quantized(dy, ody)
+            sdy8 = ody
             with rec("gemm_dgrad"):
-                general_gemm(st.weight_cache, sdy8, out_dtype=torch.bfloat16, layout="NN", grad=True)
+                general_gemm(st.weight_cache, sdy8, layout="NN", grad=True, out=dx)
             with rec("gemm_wgrad"):
-                general_gemm(sx8, sdy8, out_dtype=torch.bfloat16, layout="NT", grad=True)
+                general_gemm(sx8, sdy8, layout="NT", grad=True, out=dw)
             st.update_bwd()
 
         for _ in range(3):
