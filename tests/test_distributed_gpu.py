@@ -138,15 +138,21 @@ def _case_row(rank, world, dev, recipe_name, overlap):
         assert torch.equal(dy8_g._data, dy8_full._data)
 
 
-def _case_lnlinear(rank, world, dev, recipe_name, overlap):
+def _case_lnlinear_c4(rank, world, dev, recipe_name, overlap):
+    """BASELINE configs[3] at its per-rank shapes (Llama-3-70B QKV projection: hidden 8192 -> 10240, tokens
+    1024 per rank), run at tp = 2: every rank holds 5120 output columns instead of 1280."""
+    _case_lnlinear(rank, world, dev, recipe_name, overlap, dims=(1024, 8192, 10240), norms=("RMSNorm",))
+
+
+def _case_lnlinear(rank, world, dev, recipe_name, overlap, dims=(256, 512, 768), norms=("RMSNorm", "LayerNorm")):
     """BASELINE configs[3] shape class: LayerNormLinear, column-parallel + sequence-parallel."""
     from transformer_engine_amd import distributed as D, linear as L
-    M_local, K, N = 256, 512, 768
+    M_local, K, N = dims
     g = torch.Generator().manual_seed(7)
     x_full = torch.randn(world * M_local, K, generator=g).to(torch.bfloat16).to(dev)
     dy_full = (torch.randn(world * M_local, N, generator=g) * 0.01).to(torch.bfloat16).to(dev)
     gamma = (torch.randn(K, generator=g) * 0.2 + 1.0).to(torch.bfloat16).to(dev)
-    for norm in ("RMSNorm", "LayerNorm"):
+    for norm in norms:
         mod = D.ColumnParallelLayerNormLinearSP(K, N, world, rank, _recipe(recipe_name), device=dev, overlap=overlap,
                                                 normalization=norm, allreduce_norm_grads=True)
         mod.layer_norm_weight.copy_(gamma)
@@ -221,3 +227,7 @@ def test_row_parallel_sp_matches_unsharded(recipe_name, overlap):
 @pytest.mark.parametrize("recipe_name", ["delayed", "current"])
 def test_layernorm_linear_tp_sp_matches_unsharded(recipe_name):
     _run("lnlinear", recipe_name, True)
+
+
+def test_layernorm_linear_tp_sp_configs3_shapes():
+    _run("lnlinear_c4", "delayed", True)
