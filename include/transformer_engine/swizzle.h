@@ -24,6 +24,12 @@ void nvte_unswizzle_scaling_factors(const NVTETensor input, NVTETensor output, h
 void nvte_multi_tensor_unswizzle_scaling_factors(const NVTETensor *inputs, NVTETensor *outputs,
                                                  const size_t num_tensors, hipStream_t stream);
 
+/* ref swizzle.h:118,134.  Every member of a SAME-SHAPE MXFP8 grouped tensor: scale matrices padded to (128, 4)
+ * row-wise / (4, 128) column-wise, stored back to back per member; output's with_gemm_swizzled_scales flag
+ * must say the layout asked for.  Column-wise matrices in the transposed layout of amd_ext.h are handled too. */
+void nvte_swizzle_grouped_scaling_factors(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+void nvte_unswizzle_grouped_scaling_factors(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

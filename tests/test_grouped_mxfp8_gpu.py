@@ -228,3 +228,58 @@ def test_grouped_linear_mxfp8_fwd_bwd_matches_per_member_linear():
         assert torch.equal(dx[r0:r0 + m], dx1)
         assert torch.equal(dws[i], dw1)
         r0 += m
+
+
+@pytest.mark.parametrize("tcol", [True, False])
+def test_swizzle_grouped_scaling_factors_round_trip(tcol):
+    """nvte_swizzle_grouped_scaling_factors / nvte_unswizzle_grouped_scaling_factors (ref swizzle.h:118-134,
+    same-shape members): swizzling the compact scales of a grouped quantize gives exactly the scales the
+    quantize emits when asked for the GEMM layout directly (oracle-checked above); unswizzling returns the input."""
+    import copy
+    from transformer_engine_amd._lib import api
+    from transformer_engine_amd.tensor import current_stream_ptr
+    G, N, K = 3, 256, 384
+    w = _inputs([N] * G, K, 61, scale=0.05)
+
+    def mk(swz):
+        q = MXFP8Quantizer(E4, rowwise=True, columnwise=True, columnwise_transposed=tcol)
+        q.optimize_for_gemm = swz
+        return q
+
+    compact = group_quantize(w, mk(False), G)
+    direct = group_quantize(w, mk(True), G) if tcol else None     # (grouped quantize emits swizzled col scales for tcol only)
+    swz = copy.copy(compact)
+    swz.scale_inv = torch.zeros_like(compact.scale_inv)
+    swz.columnwise_scale_inv = torch.zeros_like(compact.columnwise_scale_inv)
+    swz.with_gemm_swizzled_scales = True
+    back = copy.copy(compact)
+    back.scale_inv = torch.zeros_like(compact.scale_inv)
+    back.columnwise_scale_inv = torch.zeros_like(compact.columnwise_scale_inv)
+    wc, ws, wb = compact.wrap(), swz.wrap(), back.wrap()
+    try:
+        api.nvte_swizzle_grouped_scaling_factors(wc.handle, ws.handle, current_stream_ptr())
+        api.nvte_unswizzle_grouped_scaling_factors(ws.handle, wb.handle, current_stream_ptr())
+    finally:
+        wc.destroy(); ws.destroy(); wb.destroy()
+    torch.cuda.synchronize()
+    assert torch.equal(back.scale_inv, compact.scale_inv)
+    assert torch.equal(back.columnwise_scale_inv, compact.columnwise_scale_inv)
+    assert not torch.equal(swz.scale_inv, compact.scale_inv)
+    if direct is not None:
+        assert torch.equal(swz.scale_inv, direct.scale_inv)
+        assert torch.equal(swz.columnwise_scale_inv, direct.columnwise_scale_inv)
+    else:
+        # reference column-wise layout: member i against the oracle's swizzle of its [N/32, K] scale matrix
+        sc = _u8(compact.columnwise_scale_inv).reshape(G, N // 32, K)
+        got = _u8(swz.columnwise_scale_inv).reshape(G, -1)
+        for i in range(G):
+            assert np.array_equal(got[i], oracle.swizzle_col_scales(sc[i]))
+    # a swizzled input to swizzle (and a compact one to unswizzle) is an error, as for single tensors
+    wc, ws = compact.wrap(), swz.wrap()
+    try:
+        with pytest.raises(NVTEError, match="already in GEMM layout"):
+            api.nvte_swizzle_grouped_scaling_factors(ws.handle, ws.handle, current_stream_ptr())
+        with pytest.raises(NVTEError, match="not in GEMM layout"):
+            api.nvte_unswizzle_grouped_scaling_factors(wc.handle, wc.handle, current_stream_ptr())
+    finally:
+        wc.destroy(); ws.destroy()

@@ -82,6 +82,8 @@ _SIGS = {
     "nvte_amd_version": (C.c_char_p, []),
     "nvte_amd_set_columnwise_transposed": (_V, [_P, _I]),
     "nvte_amd_set_grouped_columnwise_transposed": (_V, [_P, _I]),
+    "nvte_swizzle_grouped_scaling_factors": (_V, [_P, _P, _P]),
+    "nvte_unswizzle_grouped_scaling_factors": (_V, [_P, _P, _P]),
     "nvte_group_gelu": (_V, [_P, _P, _P]),
     "nvte_group_dgelu": (_V, [_P, _P, _P, _P]),
     "nvte_group_quantize_dbias_dgelu": (_V, [_P, _P, _P, _P, _P, _P]),

@@ -442,6 +442,59 @@ void swizzle_tensor(const Tensor &in, Tensor &out, bool forward, hipStream_t str
   if (has_c) swizzle_col(in.columnwise_scale_inv, out.columnwise_scale_inv, forward, stream);
 }
 
+// ref swizzle/swizzle.cu:2467-2481 (swizzle_grouped_scaling_factors): every member of a SAME-SHAPE MXFP8
+// grouped tensor, scale matrices padded to (128, 4) / (4, 128) and stored back to back.  128-row scale tiles
+// never cross members, so the row-wise matrices of all members swizzle as one stacked matrix; the
+// column-wise ones member by member (reference layout: transposing copy; transposed layout of amd_ext.h:
+// a row-type matrix per member).
+Buf scale_view(const Buf &b, size_t byte_off, size_t rows, size_t cols) {
+  Buf v = b;
+  v.ptr = static_cast<uint8_t *>(b.ptr) + byte_off;
+  v.shape = NVTEShape{{rows, cols}, 2};
+  return v;
+}
+
+void swizzle_grouped(const GroupedTensor &in, GroupedTensor &out, bool forward, hipStream_t stream) {
+  NVTE_CHECK(is_mxfp8(in.scaling_mode) && is_mxfp8(out.scaling_mode),
+             "Grouped scale swizzle is implemented for NVTE_MXFP8_1D_SCALING tensors only, got ",
+             scaling_mode_name(in.scaling_mode));
+  NVTE_CHECK(in.all_same_shape() && out.all_same_shape(), "all tensors in the grouped tensor must have the same shape");
+  NVTE_CHECK(in.num_tensors == out.num_tensors && in.logical_shape.data[0] == out.logical_shape.data[0] &&
+                 in.logical_shape.data[1] == out.logical_shape.data[1],
+             "input and output grouped tensors differ in shape");
+  NVTE_CHECK(in.with_gemm_swizzled_scales != forward,
+             forward ? "Input scales are already in GEMM layout" : "Input scales are not in GEMM layout");
+  NVTE_CHECK(out.with_gemm_swizzled_scales == forward,
+             "Output grouped tensor's with_gemm_swizzled_scales flag does not match the requested layout");
+  const size_t T = in.num_tensors, R = in.logical_shape.data[0], C = in.logical_shape.data[1];
+  NVTE_CHECK(R % T == 0, "First logical dimension must be divisible by num_tensors.");
+  const size_t first = R / T;
+  const bool has_r = in.scale_inv.present(), has_c = in.columnwise_scale_inv.present();
+  NVTE_CHECK(has_r || has_c, "Input grouped tensor has no scaling factors");
+  if (has_r) {
+    const size_t rows = round_up(first, 128), cols = round_up(ceil_div(C, 32), 4);
+    NVTE_CHECK(in.scale_inv.numel() >= T * rows * cols && out.scale_inv.numel() >= T * rows * cols,
+               "rowwise scale_inv must hold ", T, " matrices padded to (128, 4): ", T * rows * cols, " bytes");
+    Buf o = scale_view(out.scale_inv, 0, T * rows, cols);
+    swizzle_one(scale_view(in.scale_inv, 0, T * rows, cols), o, forward, "rowwise", stream);
+  }
+  if (has_c) {
+    NVTE_CHECK(in.columnwise_transposed == out.columnwise_transposed, "input and output column-wise layouts differ");
+    const size_t kb = round_up(ceil_div(first, 32), 4), n = round_up(C, 128), per = kb * n;
+    NVTE_CHECK(in.columnwise_scale_inv.numel() >= T * per && out.columnwise_scale_inv.numel() >= T * per,
+               "columnwise scale_inv must hold ", T, " matrices padded to (4, 128): ", T * per, " bytes");
+    for (size_t i = 0; i < T; ++i) {
+      if (in.columnwise_transposed) {
+        Buf o = scale_view(out.columnwise_scale_inv, i * per, n, kb);
+        swizzle_one(scale_view(in.columnwise_scale_inv, i * per, n, kb), o, forward, "columnwise (transposed)", stream);
+      } else {
+        Buf o = scale_view(out.columnwise_scale_inv, i * per, kb, n);
+        swizzle_col(scale_view(in.columnwise_scale_inv, i * per, kb, n), o, forward, stream);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 void mxfp8_quantize_launch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream) {
@@ -545,6 +598,18 @@ void nvte_multi_tensor_unswizzle_scaling_factors(const NVTETensor *inputs, NVTET
   api_guard("nvte_multi_tensor_unswizzle_scaling_factors", [&] {
     for (size_t i = 0; i < num_tensors; ++i)
       swizzle_tensor(*lookup_checked(inputs[i]), *lookup_checked(outputs[i]), false, stream);
+  });
+}
+
+void nvte_swizzle_grouped_scaling_factors(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream) {
+  api_guard("nvte_swizzle_grouped_scaling_factors", [&] {
+    swizzle_grouped(*lookup_grouped_checked(input), *lookup_grouped_checked(output), true, stream);
+  });
+}
+
+void nvte_unswizzle_grouped_scaling_factors(const NVTEGroupedTensor input, NVTEGroupedTensor output, hipStream_t stream) {
+  api_guard("nvte_unswizzle_grouped_scaling_factors", [&] {
+    swizzle_grouped(*lookup_grouped_checked(input), *lookup_grouped_checked(output), false, stream);
   });
 }
 
