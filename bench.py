@@ -375,8 +375,9 @@ def main():
                                          "reduce_scatter_bf16": rs_src.numel() * 2 * (world - 1) // world}
         result["config"]["tp_chunks"] = args.tp_chunks
 
-    if rank == 0 and world == 1:
+    if world == 1 or args.parallelism == "dp":
         # ---- per-kernel measurements (HIP events on the launch stream) -------------------------
+        # every rank runs them (the instrumented steps contain the recipe's amax all-reduce); rank 0 reports
         from transformer_engine_amd import general_gemm
         it = max(10, args.steps // 2)
         qi, qw, qg = st.fwd_q[L.FWD_INPUT], st.fwd_q[L.FWD_WEIGHT], st.bwd_q[L.BWD_GRAD_OUTPUT]
@@ -491,9 +492,9 @@ def main():
             "gemm_only_tflops": 3 * gemm_flops / ((t_fprop + t_dgrad + t_wgrad) * 1e-3) / 1e12,
             "weight_quantize_ms_not_in_step": t_ct_w,
         }
-        if not args.no_grouped:
+        if not args.no_grouped and world == 1:
             result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
             # configs[0] (the reference's CPU-runnable case: Linear 768 -> 3072, 2048 tokens) in full, CPU and GPU
             c1 = cpu_baseline(tokens=2048, K=768, N=3072)
