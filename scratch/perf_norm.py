@@ -39,6 +39,9 @@ for (N, H) in [(8192, 4096), (8192, 8192), (16384, 8192), (8192, 12288)]:
     bt = wsq.get_param(0); nb = bt.shape.data[0]
     wsb = wrap_plain(torch.empty(nb, dtype=torch.uint8, device="cuda"))
     f_bwd = lambda: api.nvte_rmsnorm_bwd(wdz.handle, wx.handle, wrs.handle, wg.handle, wdx.handle, wdg.handle, wsb.handle, 0, False, st)
-    if H <= 8192:
-        t = sorted(timeit(f_bwd) for _ in range(3))[1]
-        print(f"[{N}x{H}] rmsnorm bwd: {t*1e3:.1f} us  {N*H*6/t/1e6:.0f} GB/s (6 B/elem)")
+    db = torch.empty_like(g); wdb = wrap_plain(db)
+    f_lnb = lambda: api.nvte_layernorm_bwd(wdz.handle, wx.handle, wmu.handle, wrs.handle, wg.handle, wdx.handle, wdg.handle, wdb.handle, wsb.handle, 0, False, st)
+    if H <= 12288:
+        for name, f in (("rmsnorm bwd", f_bwd), ("layernorm bwd", f_lnb)):
+            t = sorted(timeit(f) for _ in range(3))[1]
+            print(f"[{N}x{H}] {name}: {t*1e3:.1f} us  {N*H*6/t/1e6:.0f} GB/s (6 B/elem)")

@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B: wgrad before dgrad in linear_backward
+mkdir -p gpurun_out
+for i in 1 2; do
+  timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-grouped --steps 40 > gpurun_out/r2k_base_$i.json 2>gpurun_out/r2k.err || exit $?
+  TE_AMD_WGRAD_FIRST=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-grouped --steps 40 > gpurun_out/r2k_wf_$i.json 2>gpurun_out/r2k.err || exit $?
+done
+python3 - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r2k_*.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, round(d["ms_per_step"],4), round(d["value"],1))
+PY

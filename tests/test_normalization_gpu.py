@@ -19,6 +19,9 @@ pytestmark = pytest.mark.gpu
 E4, E5 = DType.kFloat8E4M3, DType.kFloat8E5M2
 
 SHAPES = [(71, 229), (29, 541), (768, 6144), (2048, 12288), (256, 4096), (64, 8192)]   # first four: the reference's
+# rows that do not fill the vector kernels' (vectors per thread) x (threads) footprint: the guarded instantiations
+# of every workgroup width (1x256, 2x256, 3x256, 2x512, 3x512, 2x1024 threads x vectors), plus 16384 (full, 1024 threads)
+GUARDED = [(17, 1024), (33, 3072), (21, 5120), (19, 7168), (40, 10240), (13, 14336), (24, 16384)]
 
 
 def _inputs(N, H, dtype, seed):
@@ -28,7 +31,7 @@ def _inputs(N, H, dtype, seed):
     return x.contiguous(), g.contiguous(), b.contiguous()
 
 
-@pytest.mark.parametrize("N,H", SHAPES)
+@pytest.mark.parametrize("N,H", SHAPES + GUARDED)
 @pytest.mark.parametrize("kind", ["ln", "rms"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("zero_centered", [False, True])
@@ -53,7 +56,7 @@ def test_norm_fwd_high_precision(N, H, kind, dtype, zero_centered):
         assert np.allclose(out.float().cpu().numpy(), ref, rtol=8e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("N,H", [(71, 229), (768, 6144), (256, 4096), (2048, 12288)])
+@pytest.mark.parametrize("N,H", [(71, 229), (768, 6144), (256, 4096), (2048, 12288)] + GUARDED)
 @pytest.mark.parametrize("kind", ["ln", "rms"])
 @pytest.mark.parametrize("fmt", [E4, E5])
 def test_norm_fwd_fp8_delayed_scaling(N, H, kind, fmt):
@@ -86,6 +89,41 @@ def test_norm_fwd_fp8_delayed_scaling(N, H, kind, fmt):
     assert np.array_equal(u8(out._transpose), u8(out._data).T)
 
 
+@pytest.mark.parametrize("fmt", [E4, E5])
+@pytest.mark.parametrize("H", [4096, 3072])
+def test_norm_fwd_fp8_saturation_and_nan(fmt, H):
+    """A scale that pushes part of the output past the format's finite range, an infinite gamma and a NaN
+    gamma: out-of-range values saturate to +-max finite, NaN stays NaN, every other byte is what the
+    per-value saturating cast of the oracle gives (the vector kernel decides per 8 values whether any clamp
+    is needed: both of its branches are taken here)."""
+    N = 48
+    x, g, b = _inputs(N, H, torch.bfloat16, 31)
+    g[5] = float("inf")
+    g[H - 3] = float("nan")
+    big = 300.0 if fmt == E4 else 40000.0     # |y| reaches ~6: y * scale crosses 448 / 57344 on some vectors only
+    scale = torch.full((1,), big, device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    q = Float8Quantizer(scale, amax, fmt, columnwise=False)
+    out, _, _ = rmsnorm_fwd(x, g, 1e-5, quantizer=q)
+    torch.cuda.synchronize()
+    ref, _, _, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g), None, 1e-5, scale=big)
+    got_b = u8(out._data)
+    want_b = oracle.float_to_fp8(ref, FMT[fmt])
+    got = oracle.fp8_to_float(got_b, FMT[fmt])
+    want = oracle.fp8_to_float(want_b, FMT[fmt])
+    fmax = 448.0 if fmt == E4 else 57344.0
+    assert np.isnan(got[:, H - 3]).all() and np.isnan(want[:, H - 3]).all()
+    x5 = x[:, 5].float().cpu().numpy()
+    assert (np.abs(got[:, 5][x5 != 0]) == fmax).all()                 # inf saturates, sign kept
+    assert (np.sign(got[:, 5][x5 != 0]) == np.sign(x5[x5 != 0])).all()
+    sat = np.abs(want) == fmax
+    assert sat.mean() > 0.01 and (~sat).mean() > 0.5                   # both branches exercised
+    ok = ~np.isnan(want)
+    step = 2.0 ** -3 if fmt == E4 else 2.0 ** -2
+    assert (np.abs(got[ok] - want[ok]) <= step * np.abs(want[ok]) + 2.0 ** -9).all()
+    assert (got_b[ok] != want_b[ok]).mean() < 2e-3
+
+
 def test_norm_fwd_mxfp8_and_current_scaling_outputs():
     N, H = 256, 1024
     x, g, b = _inputs(N, H, torch.bfloat16, 7)
@@ -105,7 +143,7 @@ def test_norm_fwd_mxfp8_and_current_scaling_outputs():
     assert torch.equal(out._data, ref._data) and torch.equal(out._scale_inv, ref._scale_inv)
 
 
-@pytest.mark.parametrize("N,H", [(71, 229), (29, 541), (768, 6144), (512, 8192), (2048, 12288)])
+@pytest.mark.parametrize("N,H", [(71, 229), (29, 541), (768, 6144), (512, 8192), (2048, 12288), (300, 4096)] + GUARDED)
 @pytest.mark.parametrize("kind", ["ln", "rms", "rms_add"])
 @pytest.mark.parametrize("zero_centered", [False, True])
 def test_norm_bwd(N, H, kind, zero_centered):

@@ -89,6 +89,37 @@ __device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d)
   return cvt_pk_fp8<F, true>(c, d, r);
 }
 
+// Eight values t -> eight FP8 bytes of sat(t * scale), and amax = max(amax, |t|) (NaN ignored, as fmaxf).
+// The finite-range clamp of cvt_pk_fp8 costs three instructions per value; here one test of the vector's
+// largest magnitude decides for all eight: nothing to clamp (the usual case, and NaN needs no clamp: the
+// hardware conversion keeps it) -> plain conversions.  Same bytes as the per-value form in every case:
+// fl(|t| * scale) is monotonic in |t|, so the scaled largest magnitude is the largest scaled magnitude.
+template <Fp8 F>
+__device__ __forceinline__ u32x2 quantize8(const float (&t)[8], float scale, float &amax) {
+  float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t[0]), __builtin_fabsf(t[1])), __builtin_fabsf(t[2]));
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[3])), __builtin_fabsf(t[4]));
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[5])), __builtin_fabsf(t[6]));
+  m = __builtin_fmaxf(m, __builtin_fabsf(t[7]));
+  amax = __builtin_fmaxf(amax, m);
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = t[k] * scale;
+  u32x2 w;
+  if (__builtin_fabsf(m * scale) <= Fp8Traits<F>::max_finite) {
+    if constexpr (F == Fp8::E4M3) {
+      w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false), true);
+      w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false), true);
+    } else {
+      w[0] = __builtin_amdgcn_cvt_pk_bf8_f32(o[2], o[3], __builtin_amdgcn_cvt_pk_bf8_f32(o[0], o[1], 0, false), true);
+      w[1] = __builtin_amdgcn_cvt_pk_bf8_f32(o[6], o[7], __builtin_amdgcn_cvt_pk_bf8_f32(o[4], o[5], 0, false), true);
+    }
+  } else {
+    w[0] = cvt4_fp8<F>(o[0], o[1], o[2], o[3]);
+    w[1] = cvt4_fp8<F>(o[4], o[5], o[6], o[7]);
+  }
+  return w;
+}
+
 template <Fp8 F>
 __device__ __forceinline__ uint8_t cvt1_fp8(float a) {
   return static_cast<uint8_t>(cvt_pk_fp8<F, false>(a, a, 0u) & 0xFFu);

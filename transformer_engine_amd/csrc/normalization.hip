@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include <atomic>
 
@@ -52,30 +53,122 @@ __device__ __forceinline__ float round_as(float v) {
 }
 enum : int { kZE4M3 = 0, kZE5M2 = 1, kZSame = 2 };  // output kind of the vector forward kernel
 
-// Sum of (a, b) over the 256 threads of the workgroup, result in every thread.  `red` has
-// 2 x 4 x 2 floats; `phase` alternates so that consecutive reductions need one barrier each.
-__device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[4][2], unsigned &phase) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_xor(a, off, 64);
-    b += __shfl_xor(b, off, 64);
-  }
+// Sum of (a, b) over the NW waves of the workgroup, result in every thread.  `red` has
+// 2 x NW x 2 floats; `phase` alternates so that consecutive reductions need one barrier each.
+// The barrier is the bare instruction behind a wait for this wave's LDS traffic only: __syncthreads()
+// also waits for every outstanding global load and store of the wave (one counter on gfx9), which
+// would drain the next row's prefetch and the previous row's stores at every reduction.
+// Wave sum on the DPP path (cross-lane operands of ordinary vector adds) instead of six dependent
+// ds_bpermute round trips through the LDS crossbar: quad swaps, two row rotations, then the row totals
+// travel down the rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lane 63 ends
+// up with the total of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0xb1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);  // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);  // row_ror:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+template <int NW = 4>
+__device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[NW][2], unsigned &phase) {
+  a = wave_sum_to_lane63(a);
+  b = wave_sum_to_lane63(b);
   const unsigned w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63u) == 0) {
+  if ((threadIdx.x & 63u) == 63u) {
     red[phase][w][0] = a;
     red[phase][w][1] = b;
   }
-  __syncthreads();
-  a = red[phase][0][0] + red[phase][1][0] + red[phase][2][0] + red[phase][3][0];
-  b = red[phase][0][1] + red[phase][1][1] + red[phase][2][1] + red[phase][3][1];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float sa = red[phase][0][0], sb = red[phase][0][1];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) {
+    sa += red[phase][i][0];
+    sb += red[phase][i][1];
+  }
+  a = sa;
+  b = sb;
   phase ^= 1u;
 }
+
+// Eight elements of IT as they come out of memory: the next row waits in registers in this packed
+// form (4 registers for the 16-bit types) and is widened to fp32 when its turn comes.
+template <typename IT>
+struct Raw8 {
+  u32x4 v;
+  __device__ __forceinline__ void load(const IT *p) { v = ld_stream<u32x4>(p); }
+  __device__ __forceinline__ void load_cached(const IT *p) { v = *reinterpret_cast<const u32x4 *>(p); }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+    if constexpr (std::is_same_v<IT, bf16_t>) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f[2 * k] = __uint_as_float(v[k] << 16);
+        f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
+      }
+    } else {
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      const h8 h = __builtin_bit_cast(h8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(h[k]);
+    }
+  }
+};
+template <>
+struct Raw8<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ void load(const float *p) {
+    lo = ld_stream<f32x4>(p);
+    hi = ld_stream<f32x4>(p + 4);
+  }
+  __device__ __forceinline__ void load_cached(const float *p) {
+    lo = *reinterpret_cast<const f32x4 *>(p);
+    hi = *reinterpret_cast<const f32x4 *>(p + 4);
+  }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f[k] = lo[k];
+      f[4 + k] = hi[k];
+    }
+  }
+};
 
 // gamma as the kernels use it.  zc: 0 = as stored, 1 = gamma + 1 in fp32 (the reference's own kernels),
 // 2 = gamma + 1 rounded to the weight dtype (its cuDNN backend with
 // nvte_enable_zero_centered_gamma_in_weight_dtype, ref tests/cpp/operator/test_normalization.h:63-93)
 __device__ __forceinline__ float gamma_eff(const void *g, size_t i, int dtype, int zc) {
   float v = load1(g, i, dtype);
+  if (zc) v += 1.f;
+  if (zc == 2) v = round_to(v, dtype);
+  return v;
+}
+
+// Eight consecutive weights (gamma or beta) from column c as fp32: one vector load when the weights have
+// the kernel's element type IT and the buffer is 16-byte aligned (every workgroup reads them once before
+// its first row, and a workgroup only sees a handful of rows), element by element otherwise.
+template <typename IT>
+__device__ __forceinline__ void load_weights8(const void *w, unsigned c, int w_dtype, float (&out)[8]) {
+  constexpr int it_dtype = std::is_same_v<IT, bf16_t> ? kNVTEBFloat16 : std::is_same_v<IT, f16_t> ? kNVTEFloat16 : kNVTEFloat32;
+  if (w_dtype == it_dtype && (reinterpret_cast<uintptr_t>(w) & 15u) == 0) {
+    Raw8<IT> r;
+    r.load_cached(static_cast<const IT *>(w) + c);
+    r.unpack(out);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = load1(w, c + k, w_dtype);
+  }
+}
+// the zero_centered_gamma forms of gamma_eff applied to an already loaded value
+__device__ __forceinline__ float gamma_adjust(float v, int dtype, int zc) {
   if (zc) v += 1.f;
   if (zc == 2) v = round_to(v, dtype);
   return v;
@@ -95,10 +188,17 @@ struct NormFwdArgs {
 
 // IT (input) and ZK (output kind) are template parameters: a run-time dtype switch inside the unrolled
 // vector loops becomes a branch tree per vector and serialises the loads of a row.
-template <int NV, bool LN, typename IT, int ZK>
-__global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
-  __shared__ float red[2][4][2];
-  __shared__ float red_max[4];
+// NW waves per workgroup, thread t owns the 8-element vectors v * (64 NW) + t, NV <= 2 (wide rows get wide
+// workgroups); the next row is fetched (packed) as soon as the current one has been widened to fp32, so its
+// loads are in flight during the reductions and the stores of the current row.
+template <int NV, int NW, bool LN, typename IT, int ZK, bool FULL>
+__global__ __launch_bounds__(NW * 64) void norm_fwd_kernel(const NormFwdArgs a) {
+  constexpr unsigned NT = NW * 64;
+  // FULL: the row is exactly NV * NT vectors long, no thread owns a vector past its end (the guards cost
+  // an exec-mask branch and zero fills per vector otherwise)
+  auto in_row = [&](unsigned c) { return FULL || c < a.cols; };
+  __shared__ float red[2][NW][2];
+  __shared__ float red_max[NW];
   unsigned phase = 0;
   const unsigned tid = threadIdx.x;
   constexpr bool fp8_out = ZK != kZSame;
@@ -108,34 +208,50 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
   float g[NV][8], b[NV][8];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const unsigned c = (v * 256 + tid) * 8;
+    const unsigned c = (v * NT + tid) * 8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      g[v][k] = c < a.cols ? gamma_eff(a.gamma, c + k, a.w_dtype, a.zero_centered) : 0.f;
-      b[v][k] = (LN && c < a.cols) ? load1(a.beta, c + k, a.w_dtype) : 0.f;
+    for (int k = 0; k < 8; ++k) g[v][k] = b[v][k] = 0.f;
+    if (in_row(c)) {
+      load_weights8<IT>(a.gamma, c, a.w_dtype, g[v]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[v][k] = gamma_adjust(g[v][k], a.w_dtype, a.zero_centered);
+      if constexpr (LN) load_weights8<IT>(a.beta, c, a.w_dtype, b[v]);
     }
   }
+  // the packed row buffer: it is refilled with the next row as soon as the current one has been widened to
+  // fp32 (two rows ahead was measured: forward unchanged, backward 15-20 % slower)
+  Raw8<IT> rxa[NV];
+  auto fetch = [&](Raw8<IT>(&rx)[NV], unsigned row) {
+    const size_t base = static_cast<size_t>(row) * a.cols;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const unsigned c = (v * NT + tid) * 8;
+      if (in_row(c)) rx[v].load(xin + base + c);
+    }
+  };
   float amax = 0.f;
-  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) {
+  auto do_row = [&](Raw8<IT>(&rx)[NV], unsigned row) {
     const size_t base = static_cast<size_t>(row) * a.cols;
     float x[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const unsigned c = (v * 256 + tid) * 8;
-      if (c < a.cols) {
-        Load8<IT>::run(xin + base + c, x[v]);
+      const unsigned c = (v * NT + tid) * 8;
+      if (in_row(c)) {
+        rx[v].unpack(x[v]);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[v][k] = 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        s1 += x[v][k];
-        if constexpr (!LN) s2 += x[v][k] * x[v][k];
+        if constexpr (LN) s1 += x[v][k];
+        else s2 += x[v][k] * x[v][k];
       }
     }
-    block_sum2(s1, s2, red, phase);
+    const unsigned nrow = row + gridDim.x;
+    if (nrow < a.rows) fetch(rx, nrow);
+    block_sum2<NW>(s1, s2, red, phase);
     float mean = 0.f;
     if constexpr (LN) {
       // second moment about the mean, from the registers (ref test_normalization.h:44-57)
@@ -143,13 +259,13 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
       float m2 = 0.f, zero = 0.f;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        const unsigned c = (v * 256 + tid) * 8;
-        if (c < a.cols) {
+        const unsigned c = (v * NT + tid) * 8;
+        if (in_row(c)) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) m2 += (x[v][k] - mean) * (x[v][k] - mean);
         }
       }
-      block_sum2(m2, zero, red, phase);
+      block_sum2<NW>(m2, zero, red, phase);
       s2 = m2;
     }
     const float rs = rsqrtf(s2 * rn + a.eps);
@@ -159,33 +275,31 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormFwdArgs a) {
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const unsigned c = (v * 256 + tid) * 8;
-      if (c >= a.cols) continue;
+      const unsigned c = (v * NT + tid) * 8;
+      if (!in_row(c)) continue;
       float o[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float t = (x[v][k] - mean) * rs * g[v][k] + b[v][k];
-        if constexpr (fp8_out) {
-          amax = fmaxf(amax, __builtin_fabsf(t));
-          t *= scale;
-        } else {
-          if (a.amax) amax = fmaxf(amax, __builtin_fabsf(round_as<IT>(t)));
-        }
-        o[k] = t;
+        o[k] = (x[v][k] - mean) * rs * g[v][k];
+        if constexpr (LN) o[k] += b[v][k];
       }
       if constexpr (ZK == kZE4M3) {
-        u32x2 w = {cvt4_fp8<Fp8::E4M3>(o[0], o[1], o[2], o[3]), cvt4_fp8<Fp8::E4M3>(o[4], o[5], o[6], o[7])};
-        *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.z) + base + c) = w;
+        *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.z) + base + c) = quantize8<Fp8::E4M3>(o, scale, amax);
       } else if constexpr (ZK == kZE5M2) {
-        u32x2 w = {cvt4_fp8<Fp8::E5M2>(o[0], o[1], o[2], o[3]), cvt4_fp8<Fp8::E5M2>(o[4], o[5], o[6], o[7])};
-        *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.z) + base + c) = w;
+        *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.z) + base + c) = quantize8<Fp8::E5M2>(o, scale, amax);
       } else {
+        if (a.amax) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) amax = fmaxf(amax, __builtin_fabsf(round_as<IT>(o[k])));
+        }
         store8_t<IT>(static_cast<IT *>(a.z) + base + c, o);
       }
     }
-  }
+  };
+  if (blockIdx.x < a.rows) fetch(rxa, blockIdx.x);
+  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) do_row(rxa, row);
   if (a.amax) {
-    amax = block_max<4>(amax, red_max);
+    amax = block_max<NW>(amax, red_max);
     if (tid == 0) atomic_max_nonneg(a.amax, amax);
   }
   if (fp8_out && blockIdx.x == 0 && tid == 0 && a.scale_inv) *a.scale_inv = 1.f / scale;
@@ -259,39 +373,66 @@ struct NormBwdArgs {
 
 // dx = rs * (dy - mean(dy*y) * y - mean(dy)) (+ add), dy = gamma' * dz, y = (x - mu) * rs
 // (ref tests/cpp/operator/test_normalization.h:140-190); per-workgroup partial dgamma / dbeta.
-template <int NV, bool LN, typename IT>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
-  __shared__ float red[2][4][2];
+// NW waves per workgroup, thread t owns the 8-element vectors v * (64 NW) + t (NV <= 2 of them: wider
+// rows get wider workgroups, not more registers per thread).  The next row's x / dz (and mu / rsigma)
+// are fetched while the current row is reduced and written, so a workgroup always has two rows of
+// loads in flight.
+template <int NV, int NW, bool LN, typename IT, bool FULL>
+__global__ __launch_bounds__(NW * 64) void norm_bwd_kernel(const NormBwdArgs a) {
+  constexpr unsigned NT = NW * 64;
+  auto in_row = [&](unsigned c) { return FULL || c < a.cols; };
+  __shared__ float red[2][NW][2];
   unsigned phase = 0;
   const unsigned tid = threadIdx.x;
   const float rn = 1.f / static_cast<float>(a.cols);
   float g[NV][8], dg[NV][8], db[NV][8];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const unsigned c = (v * 256 + tid) * 8;
+    const unsigned c = (v * NT + tid) * 8;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      g[v][k] = c < a.cols ? gamma_eff(a.gamma, c + k, a.w_dtype, a.zero_centered) : 0.f;
-      dg[v][k] = 0.f;
-      db[v][k] = 0.f;
+    for (int k = 0; k < 8; ++k) g[v][k] = dg[v][k] = db[v][k] = 0.f;
+    if (in_row(c)) {
+      load_weights8<IT>(a.gamma, c, a.w_dtype, g[v]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[v][k] = gamma_adjust(g[v][k], a.w_dtype, a.zero_centered);
     }
   }
-  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) {
+  // the packed row buffer (x, dz, mu, rsigma of a row): refilled with the next row as soon as the current one
+  // has been widened to fp32
+  struct RowBuf {
+    Raw8<IT> x[NV], dz[NV];
+    float mean, rs;
+  };
+  RowBuf bufa;
+  auto fetch = [&](RowBuf &rb, unsigned row) {
     const size_t base = static_cast<size_t>(row) * a.cols;
-    const float mean = LN ? a.mu[row] : 0.f, rs = a.rs[row];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const unsigned c = (v * NT + tid) * 8;
+      if (in_row(c)) {
+        rb.x[v].load(static_cast<const IT *>(a.x) + base + c);
+        rb.dz[v].load(static_cast<const IT *>(a.dz) + base + c);
+      }
+    }
+    rb.mean = LN ? a.mu[row] : 0.f;
+    rb.rs = a.rs[row];
+  };
+  auto do_row = [&](RowBuf &rb, unsigned row) {
+    const size_t base = static_cast<size_t>(row) * a.cols;
+    const float mean = rb.mean, rs = rb.rs;
     float y[NV][8], dy[NV][8];
     float sdy = 0.f, sdyy = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const unsigned c = (v * 256 + tid) * 8;
+      const unsigned c = (v * NT + tid) * 8;
       float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dzv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (c < a.cols) {
-        Load8<IT>::run(static_cast<const IT *>(a.x) + base + c, xv);
-        Load8<IT>::run(static_cast<const IT *>(a.dz) + base + c, dzv);
+      if (in_row(c)) {
+        rb.x[v].unpack(xv);
+        rb.dz[v].unpack(dzv);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        y[v][k] = c < a.cols ? (xv[k] - mean) * rs : 0.f;
+        y[v][k] = in_row(c) ? (xv[k] - mean) * rs : 0.f;
         dy[v][k] = g[v][k] * dzv[k];
         dg[v][k] += y[v][k] * dzv[k];
         if constexpr (LN) {
@@ -301,24 +442,36 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormBwdArgs a) {
         sdyy += dy[v][k] * y[v][k];
       }
     }
-    block_sum2(sdy, sdyy, red, phase);
+    const unsigned nrow = row + gridDim.x;
+    if (nrow < a.rows) fetch(rb, nrow);
+    Raw8<IT> radd[NV];
+    if (a.add) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const unsigned c = (v * NT + tid) * 8;
+        if (in_row(c)) radd[v].load(static_cast<const IT *>(a.add) + base + c);
+      }
+    }
+    block_sum2<NW>(sdy, sdyy, red, phase);
     const float mdy = sdy * rn, mdyy = sdyy * rn;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const unsigned c = (v * 256 + tid) * 8;
-      if (c >= a.cols) continue;
+      const unsigned c = (v * NT + tid) * 8;
+      if (!in_row(c)) continue;
       float o[8], ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.add) Load8<IT>::run(static_cast<const IT *>(a.add) + base + c, ad);
+      if (a.add) radd[v].unpack(ad);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = ad[k] + rs * (dy[v][k] - mdyy * y[v][k] - mdy);
       store8_t<IT>(static_cast<IT *>(a.dx) + base + c, o);
     }
-  }
+  };
+  if (blockIdx.x < a.rows) fetch(bufa, blockIdx.x);
+  for (unsigned row = blockIdx.x; row < a.rows; row += gridDim.x) do_row(bufa, row);
   float *pg = a.part + static_cast<size_t>(blockIdx.x) * 2 * a.cols;
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
-    const unsigned c = (v * 256 + tid) * 8;
-    if (c >= a.cols) continue;
+    const unsigned c = (v * NT + tid) * 8;
+    if (!in_row(c)) continue;
     f32x4 lo = {dg[v][0], dg[v][1], dg[v][2], dg[v][3]}, hi = {dg[v][4], dg[v][5], dg[v][6], dg[v][7]};
     *reinterpret_cast<f32x4 *>(pg + c) = lo;
     *reinterpret_cast<f32x4 *>(pg + c + 4) = hi;
@@ -369,55 +522,87 @@ __global__ __launch_bounds__(256) void norm_bwd_general_kernel(const NormBwdArgs
   }
 }
 
-// dgamma[c] = sum over workgroups of part[b][0][c]; dbeta likewise from part[b][1][c]
-// One workgroup per 64 columns: wave w sums the partials of workgroups w, w + 4, ... (a wave reads 256
-// contiguous bytes per partial row, four rows in flight), the 4 waves meet in LDS.
-__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(const float *part, unsigned nblocks, unsigned cols,
-                                                                void *dgamma, void *dbeta, int w_dtype) {
-  __shared__ float acc[2][4][64];
+// dgamma[c] = sum over workgroups of part[b][0][c]; dbeta likewise from part[b][1][c].
+// One 16-wave workgroup per 32 columns: a half wave reads one 128-byte line of a partial row, the 32
+// half waves take the rows b = h, h + 32, ... with eight of them in flight each (the partial rows sit in
+// the Infinity Cache: what bounds this kernel is how many lines it has in flight, not their bytes),
+// then the 32 sums per column meet in LDS in a fixed order.
+__global__ __launch_bounds__(1024) void norm_bwd_finalize_kernel(const float *part, unsigned nblocks, unsigned cols,
+                                                                 void *dgamma, void *dbeta, int w_dtype) {
+  __shared__ float acc[2][32][33];
   const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-  const unsigned c = blockIdx.x * 64 + lane;
+  const unsigned h = w * 2 + (lane >> 5), cl = lane & 31u;
+  const unsigned c = blockIdx.x * 32 + cl;
   float sg = 0.f, sb = 0.f;
   if (c < cols) {
-#pragma unroll 4
-    for (unsigned b = w; b < nblocks; b += 4) {
-      sg += part[static_cast<size_t>(b) * 2 * cols + c];
-      if (dbeta) sb += part[static_cast<size_t>(b) * 2 * cols + cols + c];
+    const float *p = part + c;
+    const size_t stride = static_cast<size_t>(2) * cols;
+    if (dbeta) {
+#pragma unroll 8
+      for (unsigned b = h; b < nblocks; b += 32) {
+        sg += p[b * stride];
+        sb += p[b * stride + cols];
+      }
+    } else {
+#pragma unroll 8
+      for (unsigned b = h; b < nblocks; b += 32) sg += p[b * stride];
     }
   }
-  acc[0][w][lane] = sg;
-  acc[1][w][lane] = sb;
+  acc[0][h][cl] = sg;
+  acc[1][h][cl] = sb;
   __syncthreads();
-  if (w == 0 && c < cols) {
-    store1(dgamma, c, w_dtype, acc[0][0][lane] + acc[0][1][lane] + acc[0][2][lane] + acc[0][3][lane]);
-    if (dbeta) store1(dbeta, c, w_dtype, acc[1][0][lane] + acc[1][1][lane] + acc[1][2][lane] + acc[1][3][lane]);
+  if (threadIdx.x < 64) {
+    const unsigned which = threadIdx.x >> 5;  // 0: dgamma, 1: dbeta
+    const unsigned col = blockIdx.x * 32 + cl;
+    if (col < cols && (which == 0 || dbeta)) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) t += acc[which][i][cl];
+      store1(which == 0 ? dgamma : dbeta, col, w_dtype, t);
+    }
   }
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Persistent workgroups: as many per CU as the kernel's register use lets run at once
-// (forward: 46-56 / 70-76 / 121-128 / 225-232 VGPRs for 1 / 2 / 4 / 8 vectors per thread).
+// Persistent workgroups: as many per CU as the kernel's register use lets run at once (asked of the
+// runtime once per kernel instantiation).
 unsigned norm_grid(size_t rows, unsigned per_cu) {
   const size_t want = static_cast<size_t>(device_info().num_cus) * per_cu;
   return static_cast<unsigned>(std::max<size_t>(1, std::min(rows, want)));
 }
+template <typename K>
+unsigned resident_per_cu(K kernel, unsigned threads) {
+  int n = 0;
+  NVTE_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, static_cast<int>(threads), 0));
+  return static_cast<unsigned>(std::max(1, n));
+}
 
 bool shape_is_2d(const Buf &b) { return b.shape.ndim == 2; }
 
+template <int NV, int NW, bool LN, typename IT, int ZK, bool FULL>
+void launch_fwd_full(const NormFwdArgs &args, hipStream_t stream) {
+  static const unsigned per_cu = resident_per_cu(norm_fwd_kernel<NV, NW, LN, IT, ZK, FULL>, NW * 64);
+  hipLaunchKernelGGL((norm_fwd_kernel<NV, NW, LN, IT, ZK, FULL>), dim3(norm_grid(args.rows, per_cu)), dim3(NW * 64), 0,
+                     stream, args);
+}
+template <int NV, int NW, bool LN, typename IT, int ZK>
+void launch_fwd_one(const NormFwdArgs &args, hipStream_t stream) {
+  if (args.cols == NV * NW * 512u) launch_fwd_full<NV, NW, LN, IT, ZK, true>(args, stream);
+  else launch_fwd_full<NV, NW, LN, IT, ZK, false>(args, stream);
+}
+// (vectors per thread, waves): the narrowest workgroup whose threads hold the row in at most three vectors;
+// rows of exactly NV * NW * 512 elements (2048, 4096, 6144, 8192, 12288, 16384) run without guards.
+// Measured against one-vector threads in twice as wide workgroups: equal for RMSNorm, LayerNorm 15-25 %
+// faster this way at 8192 columns.
 template <bool LN, typename IT, int ZK>
 void launch_fwd_vec(const NormFwdArgs &args, hipStream_t stream) {
-  const unsigned per_cu = args.cols <= 2048 ? 8 : args.cols <= 4096 ? 6 : args.cols <= 8192 ? 4 : 2;
-  const dim3 grid(norm_grid(args.rows, per_cu)), block(256);
-  if (args.cols <= 2048) {
-    hipLaunchKernelGGL((norm_fwd_kernel<1, LN, IT, ZK>), grid, block, 0, stream, args);
-  } else if (args.cols <= 4096) {
-    hipLaunchKernelGGL((norm_fwd_kernel<2, LN, IT, ZK>), grid, block, 0, stream, args);
-  } else if (args.cols <= 8192) {
-    hipLaunchKernelGGL((norm_fwd_kernel<4, LN, IT, ZK>), grid, block, 0, stream, args);
-  } else {
-    hipLaunchKernelGGL((norm_fwd_kernel<8, LN, IT, ZK>), grid, block, 0, stream, args);
-  }
+  if (args.cols <= 2048) launch_fwd_one<1, 4, LN, IT, ZK>(args, stream);
+  else if (args.cols <= 4096) launch_fwd_one<2, 4, LN, IT, ZK>(args, stream);
+  else if (args.cols <= 6144) launch_fwd_one<3, 4, LN, IT, ZK>(args, stream);
+  else if (args.cols <= 8192) launch_fwd_one<2, 8, LN, IT, ZK>(args, stream);
+  else if (args.cols <= 12288) launch_fwd_one<3, 8, LN, IT, ZK>(args, stream);
+  else launch_fwd_one<2, 16, LN, IT, ZK>(args, stream);
 }
 
 template <bool LN, typename IT>
@@ -443,22 +628,26 @@ void launch_fwd(const NormFwdArgs &args, bool vec, hipStream_t stream) {
   NVTE_CHECK_HIP(hipGetLastError());
 }
 
+template <int NV, int NW, bool LN, typename IT>
+void launch_bwd_one(const NormBwdArgs &args, unsigned nblocks, hipStream_t stream) {
+  if (args.cols == NV * NW * 512u)
+    hipLaunchKernelGGL((norm_bwd_kernel<NV, NW, LN, IT, true>), dim3(nblocks), dim3(NW * 64), 0, stream, args);
+  else
+    hipLaunchKernelGGL((norm_bwd_kernel<NV, NW, LN, IT, false>), dim3(nblocks), dim3(NW * 64), 0, stream, args);
+}
 template <bool LN, typename IT>
 void launch_bwd_vec(const NormBwdArgs &args, unsigned nblocks, hipStream_t stream) {
-  const dim3 grid(nblocks), block(256);
-  if (args.cols <= 2048) {
-    hipLaunchKernelGGL((norm_bwd_kernel<1, LN, IT>), grid, block, 0, stream, args);
-  } else if (args.cols <= 4096) {
-    hipLaunchKernelGGL((norm_bwd_kernel<2, LN, IT>), grid, block, 0, stream, args);
-  } else {
-    hipLaunchKernelGGL((norm_bwd_kernel<4, LN, IT>), grid, block, 0, stream, args);
-  }
+  if (args.cols <= 2048) launch_bwd_one<1, 4, LN, IT>(args, nblocks, stream);
+  else if (args.cols <= 4096) launch_bwd_one<2, 4, LN, IT>(args, nblocks, stream);
+  else if (args.cols <= 8192) launch_bwd_one<2, 8, LN, IT>(args, nblocks, stream);
+  else if constexpr (!std::is_same_v<IT, float>) launch_bwd_one<3, 8, LN, IT>(args, nblocks, stream);
 }
 
 // vec additionally needs dz / add in x's dtype (w_dtype == x_dtype, the usual case)
 template <bool LN>
 void launch_bwd(const NormBwdArgs &args, unsigned nblocks, bool vec, hipStream_t stream) {
-  if (vec && args.w_dtype == args.x_dtype) {
+  // (fp32 rows of more than 8192 elements would need three 32-byte vectors per thread: spills)
+  if (vec && args.w_dtype == args.x_dtype && (args.x_dtype != kNVTEFloat32 || args.cols <= 8192)) {
     switch (args.x_dtype) {
       case kNVTEBFloat16: launch_bwd_vec<LN, bf16_t>(args, nblocks, stream); break;
       case kNVTEFloat16: launch_bwd_vec<LN, f16_t>(args, nblocks, stream); break;
@@ -642,10 +831,10 @@ void norm_bwd(bool is_ln, const Tensor &dz, const Tensor &x, const Tensor *mu, c
   a.x_dtype = x.data.dtype;
   a.w_dtype = gamma.data.dtype;
   a.zero_centered = zero_centered_gamma ? ((g_zc_in_wdtype.load() && g_cudnn_bwd.load()) ? 2 : 1) : 0;
-  const bool vec = cols % 8 == 0 && cols <= 8192 && aligned16(a.x) && aligned16(a.dz) && aligned16(a.dx) &&
+  const bool vec = cols % 8 == 0 && cols <= 12288 && aligned16(a.x) && aligned16(a.dz) && aligned16(a.dx) &&
                    (!a.add || aligned16(a.add));
   if (is_ln) launch_bwd<true>(a, nblocks, vec, stream); else launch_bwd<false>(a, nblocks, vec, stream);
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 64))), dim3(256), 0, stream,
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(static_cast<unsigned>(ceil_div(cols, 32))), dim3(1024), 0, stream,
                      a.part, nblocks, a.cols, dgamma->data.ptr, is_ln ? dbeta->data.ptr : nullptr, a.w_dtype);
   NVTE_CHECK_HIP(hipGetLastError());
 }
