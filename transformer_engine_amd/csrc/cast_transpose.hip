@@ -95,10 +95,9 @@ __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
     for (int i = 0; i < 8; ++i) {
       float f[8];
       cur[i].widen8(f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, __builtin_fabsf(f[j]));
-      q[i][0] = cvt4_fp8<F>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
-      q[i][1] = cvt4_fp8<F>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+      const u32x2 w = quantize8<F>(f, scale, amax);   // amax of the unscaled values, sat(f * scale)
+      q[i][0] = w[0];
+      q[i][1] = w[1];
       if constexpr (DBIAS) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) csum[j] += f[j];

@@ -268,7 +268,12 @@ __device__ __forceinline__ void store_tile_transposed(uint8_t *tile_t, uint32_t 
       *reinterpret_cast<u32x2 *>(&tile_t[c * 128 + ((rg ^ cg) << 3)]) = v;
     }
   }
-  __syncthreads();
+  // the bare barrier behind a wait for this wave's LDS writes only: __syncthreads() would also wait for every
+  // outstanding global access of the wave (one counter on gfx9), i.e. drain the next tile's prefetch and
+  // the rowwise stores just issued
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   const unsigned k = t & 7u;  // 16-row chunk of the output row
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -298,6 +303,7 @@ struct Raw8<bf16_t> {
   u32x4 v;
   static __device__ __forceinline__ Raw8 zero() { return Raw8{u32x4{0u, 0u, 0u, 0u}}; }
   static __device__ __forceinline__ Raw8 load(const bf16_t *p) { return Raw8{ld_stream<u32x4>(p)}; }
+  static __device__ __forceinline__ Raw8 load_cached(const bf16_t *p) { return Raw8{*reinterpret_cast<const u32x4 *>(p)}; }
   __device__ __forceinline__ void widen8(float (&f)[8]) const {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -312,6 +318,7 @@ struct Raw8<f16_t> {
   h8 v;
   static __device__ __forceinline__ Raw8 zero() { return Raw8{h8{0, 0, 0, 0, 0, 0, 0, 0}}; }
   static __device__ __forceinline__ Raw8 load(const f16_t *p) { return Raw8{ld_stream<h8>(p)}; }
+  static __device__ __forceinline__ Raw8 load_cached(const f16_t *p) { return Raw8{*reinterpret_cast<const h8 *>(p)}; }
   __device__ __forceinline__ void widen8(float (&f)[8]) const {
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(v[k]);
@@ -322,6 +329,9 @@ struct Raw8<float> {
   f32x4 a, b;
   static __device__ __forceinline__ Raw8 zero() { return Raw8{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}; }
   static __device__ __forceinline__ Raw8 load(const float *p) { return Raw8{ld_stream<f32x4>(p), ld_stream<f32x4>(p + 4)}; }
+  static __device__ __forceinline__ Raw8 load_cached(const float *p) {
+    return Raw8{*reinterpret_cast<const f32x4 *>(p), *reinterpret_cast<const f32x4 *>(p + 4)};
+  }
   __device__ __forceinline__ void widen8(float (&f)[8]) const {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

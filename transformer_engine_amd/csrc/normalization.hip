@@ -100,48 +100,6 @@ __device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[NW][
   phase ^= 1u;
 }
 
-// Eight elements of IT as they come out of memory: the next row waits in registers in this packed
-// form (4 registers for the 16-bit types) and is widened to fp32 when its turn comes.
-template <typename IT>
-struct Raw8 {
-  u32x4 v;
-  __device__ __forceinline__ void load(const IT *p) { v = ld_stream<u32x4>(p); }
-  __device__ __forceinline__ void load_cached(const IT *p) { v = *reinterpret_cast<const u32x4 *>(p); }
-  __device__ __forceinline__ void unpack(float (&f)[8]) const {
-    if constexpr (std::is_same_v<IT, bf16_t>) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        f[2 * k] = __uint_as_float(v[k] << 16);
-        f[2 * k + 1] = __uint_as_float(v[k] & 0xFFFF0000u);
-      }
-    } else {
-      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-      const h8 h = __builtin_bit_cast(h8, v);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = static_cast<float>(h[k]);
-    }
-  }
-};
-template <>
-struct Raw8<float> {
-  f32x4 lo, hi;
-  __device__ __forceinline__ void load(const float *p) {
-    lo = ld_stream<f32x4>(p);
-    hi = ld_stream<f32x4>(p + 4);
-  }
-  __device__ __forceinline__ void load_cached(const float *p) {
-    lo = *reinterpret_cast<const f32x4 *>(p);
-    hi = *reinterpret_cast<const f32x4 *>(p + 4);
-  }
-  __device__ __forceinline__ void unpack(float (&f)[8]) const {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      f[k] = lo[k];
-      f[4 + k] = hi[k];
-    }
-  }
-};
-
 // gamma as the kernels use it.  zc: 0 = as stored, 1 = gamma + 1 in fp32 (the reference's own kernels),
 // 2 = gamma + 1 rounded to the weight dtype (its cuDNN backend with
 // nvte_enable_zero_centered_gamma_in_weight_dtype, ref tests/cpp/operator/test_normalization.h:63-93)
@@ -159,9 +117,7 @@ template <typename IT>
 __device__ __forceinline__ void load_weights8(const void *w, unsigned c, int w_dtype, float (&out)[8]) {
   constexpr int it_dtype = std::is_same_v<IT, bf16_t> ? kNVTEBFloat16 : std::is_same_v<IT, f16_t> ? kNVTEFloat16 : kNVTEFloat32;
   if (w_dtype == it_dtype && (reinterpret_cast<uintptr_t>(w) & 15u) == 0) {
-    Raw8<IT> r;
-    r.load_cached(static_cast<const IT *>(w) + c);
-    r.unpack(out);
+    Raw8<IT>::load_cached(static_cast<const IT *>(w) + c).widen8(out);
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) out[k] = load1(w, c + k, w_dtype);
@@ -226,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void norm_fwd_kernel(const NormFwdArgs a) 
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const unsigned c = (v * NT + tid) * 8;
-      if (in_row(c)) rx[v].load(xin + base + c);
+      if (in_row(c)) rx[v] = Raw8<IT>::load(xin + base + c);
     }
   };
   float amax = 0.f;
@@ -238,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void norm_fwd_kernel(const NormFwdArgs a) 
     for (int v = 0; v < NV; ++v) {
       const unsigned c = (v * NT + tid) * 8;
       if (in_row(c)) {
-        rx[v].unpack(x[v]);
+        rx[v].widen8(x[v]);
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[v][k] = 0.f;
@@ -410,8 +366,8 @@ __global__ __launch_bounds__(NW * 64) void norm_bwd_kernel(const NormBwdArgs a) 
     for (int v = 0; v < NV; ++v) {
       const unsigned c = (v * NT + tid) * 8;
       if (in_row(c)) {
-        rb.x[v].load(static_cast<const IT *>(a.x) + base + c);
-        rb.dz[v].load(static_cast<const IT *>(a.dz) + base + c);
+        rb.x[v] = Raw8<IT>::load(static_cast<const IT *>(a.x) + base + c);
+        rb.dz[v] = Raw8<IT>::load(static_cast<const IT *>(a.dz) + base + c);
       }
     }
     rb.mean = LN ? a.mu[row] : 0.f;
@@ -427,8 +383,8 @@ __global__ __launch_bounds__(NW * 64) void norm_bwd_kernel(const NormBwdArgs a) 
       const unsigned c = (v * NT + tid) * 8;
       float xv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dzv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (in_row(c)) {
-        rb.x[v].unpack(xv);
-        rb.dz[v].unpack(dzv);
+        rb.x[v].widen8(xv);
+        rb.dz[v].widen8(dzv);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -449,7 +405,7 @@ __global__ __launch_bounds__(NW * 64) void norm_bwd_kernel(const NormBwdArgs a) 
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         const unsigned c = (v * NT + tid) * 8;
-        if (in_row(c)) radd[v].load(static_cast<const IT *>(a.add) + base + c);
+        if (in_row(c)) radd[v] = Raw8<IT>::load(static_cast<const IT *>(a.add) + base + c);
       }
     }
     block_sum2<NW>(sdy, sdyy, red, phase);
@@ -459,7 +415,7 @@ __global__ __launch_bounds__(NW * 64) void norm_bwd_kernel(const NormBwdArgs a) 
       const unsigned c = (v * NT + tid) * 8;
       if (!in_row(c)) continue;
       float o[8], ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (a.add) radd[v].unpack(ad);
+      if (a.add) radd[v].widen8(ad);
 #pragma unroll
       for (int k = 0; k < 8; ++k) o[k] = ad[k] + rs * (dy[v][k] - mdyy * y[v][k] - mdy);
       store8_t<IT>(static_cast<IT *>(a.dx) + base + c, o);
