@@ -89,23 +89,16 @@ __device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d)
   return cvt_pk_fp8<F, true>(c, d, r);
 }
 
-// Eight values t -> eight FP8 bytes of sat(t * scale), and amax = max(amax, |t|) (NaN ignored, as fmaxf).
-// The finite-range clamp of cvt_pk_fp8 costs three instructions per value; here one test of the vector's
-// largest magnitude decides for all eight: nothing to clamp (the usual case, and NaN needs no clamp: the
-// hardware conversion keeps it) -> plain conversions.  Same bytes as the per-value form in every case:
-// fl(|t| * scale) is monotonic in |t|, so the scaled largest magnitude is the largest scaled magnitude.
+// Eight values -> eight FP8 bytes.  The finite-range clamp of cvt_pk_fp8 costs three instructions per value
+// (compare, copysign, select, plus VCC wait states); a caller that already knows the largest magnitude of
+// the values (it computed an amax over them anyway) passes in_range = "that magnitude is inside the format's
+// finite range" and the plain hardware conversions run.  NaN needs no clamp (the conversion keeps it) and
+// is ignored by fmaxf, +-inf is larger than every range and takes the clamping branch: same bytes as the
+// per-value form in every case.
 template <Fp8 F>
-__device__ __forceinline__ u32x2 quantize8(const float (&t)[8], float scale, float &amax) {
-  float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t[0]), __builtin_fabsf(t[1])), __builtin_fabsf(t[2]));
-  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[3])), __builtin_fabsf(t[4]));
-  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[5])), __builtin_fabsf(t[6]));
-  m = __builtin_fmaxf(m, __builtin_fabsf(t[7]));
-  amax = __builtin_fmaxf(amax, m);
-  float o[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = t[k] * scale;
+__device__ __forceinline__ u32x2 cvt8_fp8(const float (&o)[8], bool in_range) {
   u32x2 w;
-  if (__builtin_fabsf(m * scale) <= Fp8Traits<F>::max_finite) {
+  if (in_range) {
     if constexpr (F == Fp8::E4M3) {
       w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], 0, false), true);
       w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], 0, false), true);
@@ -118,6 +111,24 @@ __device__ __forceinline__ u32x2 quantize8(const float (&t)[8], float scale, flo
     w[1] = cvt4_fp8<F>(o[4], o[5], o[6], o[7]);
   }
   return w;
+}
+// largest magnitude of eight values (NaN ignored, as fmaxf)
+__device__ __forceinline__ float absmax8(const float (&t)[8]) {
+  float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(t[0]), __builtin_fabsf(t[1])), __builtin_fabsf(t[2]));
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[3])), __builtin_fabsf(t[4]));
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[5])), __builtin_fabsf(t[6]));
+  return __builtin_fmaxf(m, __builtin_fabsf(t[7]));
+}
+// Eight values t -> eight FP8 bytes of sat(t * scale), and amax = max(amax, |t|).  fl(|t| * scale) is
+// monotonic in |t|, so the scaled largest magnitude is the largest scaled magnitude.
+template <Fp8 F>
+__device__ __forceinline__ u32x2 quantize8(const float (&t)[8], float scale, float &amax) {
+  const float m = absmax8(t);
+  amax = __builtin_fmaxf(amax, m);
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = t[k] * scale;
+  return cvt8_fp8<F>(o, __builtin_fabsf(m * scale) <= Fp8Traits<F>::max_finite);
 }
 
 template <Fp8 F>

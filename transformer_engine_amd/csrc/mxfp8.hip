@@ -102,8 +102,12 @@ __global__ __launch_bounds__(256) void mxfp8_tile_kernel(
       tmax = fmaxf(tmax, m);
       const uint8_t e = float_to_e8m0(m * rcp_max);
       const float r = e8m0_rcp(e);
-      u32x2 q = {cvt4_fp8<F>(f[i][0] * r, f[i][1] * r, f[i][2] * r, f[i][3] * r),
-                 cvt4_fp8<F>(f[i][4] * r, f[i][5] * r, f[i][6] * r, f[i][7] * r)};
+      // the block's largest magnitude times its own reciprocal scale is inside the range unless the block
+      // holds an infinity: no per-value clamp then (cvt8_fp8)
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f[i][j] * r;
+      const u32x2 q = cvt8_fp8<F>(o, m * r <= Fp8Traits<F>::max_finite);
       *reinterpret_cast<u32x2 *>(out_row + (row0 + i) * cols + col0) = q;
       // gather the 4 block scales of this row's 128-column segment into lane cg == 0
       uint32_t e32 = e;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void mxfp8_tile_kernel(
   if constexpr (COL) {
     uint32_t qc[8][2];
     uint32_t ebytes[2] = {0u, 0u};
+    bool in_range = true;   // every one of this thread's 8 column blocks scales into the finite range
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float m = 0.f;
@@ -133,13 +138,15 @@ __global__ __launch_bounds__(256) void mxfp8_tile_kernel(
       const uint8_t e = float_to_e8m0(m * rcp_max);
       ebytes[j >> 2] |= static_cast<uint32_t>(e) << (8 * (j & 3));
       const float r = e8m0_rcp(e);
+      in_range = in_range && (m * r <= Fp8Traits<F>::max_finite);
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i][j] *= r;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      qc[i][0] = cvt4_fp8<F>(f[i][0], f[i][1], f[i][2], f[i][3]);
-      qc[i][1] = cvt4_fp8<F>(f[i][4], f[i][5], f[i][6], f[i][7]);
+      const u32x2 w = cvt8_fp8<F>(f[i], in_range);
+      qc[i][0] = w[0];
+      qc[i][1] = w[1];
       if constexpr (!TCOL) {
         u32x2 q = {qc[i][0], qc[i][1]};
         *reinterpret_cast<u32x2 *>(out_col + (row0 + i) * cols + col0) = q;
