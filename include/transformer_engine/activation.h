@@ -58,6 +58,30 @@ void nvte_clamped_dswiglu(const NVTETensor grad, const NVTETensor input, NVTETen
 void nvte_clamped_dswiglu_v2(const NVTETensor grad, const NVTETensor input, NVTETensor output, float limit,
                              float alpha, float glu_linear_offset, hipStream_t stream);
 
+/* Activations multiplied by a per-row scale (MoE router probabilities), ref activation.h:372-406 (forward),
+ * :513-552 (backward), :590-615 (SReLU); kernels ref common/activation/scaled_activation.cu.
+ *   out[N, H] = Act(input) * act_scales[:, None], all math in fp32, one cast at the store.
+ * input [N, 2H] for the gated forms: [act | gate], or with glu_interleave_size = S (a positive multiple of 32
+ * that divides H; 0 = not interleaved) blocks [act[0:S] | gate[0:S] | act[S:2S] | ...].  input, act_scales,
+ * output / grad_input and grad_act_scales are FP32 / BF16 / FP16, each with its own dtype (no FP8 here, as in
+ * the reference).  Backward: grad_input has input's shape; grad_act_scales may be NULL, otherwise it receives
+ * sum(grad * Act(input), dim=-1) of shape [N].  The clamped forms take nvte_clamped_swiglu_v2's limit,
+ * alpha and glu_linear_offset. */
+void nvte_scaled_swiglu(const NVTETensor input, const NVTETensor act_scales, NVTETensor output,
+                        int64_t glu_interleave_size, hipStream_t stream);
+void nvte_scaled_clamped_swiglu(const NVTETensor input, const NVTETensor act_scales, NVTETensor output, float limit,
+                                float alpha, float glu_linear_offset, int64_t glu_interleave_size,
+                                hipStream_t stream);
+void nvte_scaled_dswiglu(const NVTETensor grad, const NVTETensor input, const NVTETensor act_scales,
+                         NVTETensor grad_input, NVTETensor grad_act_scales, int64_t glu_interleave_size,
+                         hipStream_t stream);
+void nvte_scaled_clamped_dswiglu(const NVTETensor grad, const NVTETensor input, const NVTETensor act_scales,
+                                 NVTETensor grad_input, NVTETensor grad_act_scales, float limit, float alpha,
+                                 float glu_linear_offset, int64_t glu_interleave_size, hipStream_t stream);
+void nvte_scaled_srelu(const NVTETensor input, const NVTETensor act_scales, NVTETensor output, hipStream_t stream);
+void nvte_scaled_dsrelu(const NVTETensor grad, const NVTETensor input, const NVTETensor act_scales,
+                        NVTETensor grad_input, NVTETensor grad_act_scales, hipStream_t stream);
+
 /* Grouped forms (ref activation.h:65,86,107,128,149): the unary activation of every member of a grouped
  * tensor, cast as output's scaling mode asks - FP8 per-tensor scaling with output.scale[i] per member (amax /
  * scale_inv untouched, as nvte_group_quantize) or MXFP8 (rows of every member and the last dim multiples of

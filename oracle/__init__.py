@@ -364,6 +364,68 @@ def clamped_swiglu(x: np.ndarray, grad=None, *, limit: float, alpha: float, offs
     return out
 
 
+def scaled_activation(kind: str, x: np.ndarray, scales: np.ndarray, grad=None, *, interleave: int = 0,
+                      limit: float = 0.5, alpha: float = 1.702, offset: float = 0.5):
+    """Activation times a per-row scale and its backward, fp32 numpy restatement of the reference's own host
+    oracle tests/cpp/operator/test_scaled_activation.cu:46-133 (glu_indices, gated_grads, compute_reference;
+    activation forms tests/cpp/test_common.h:522-531).  kind: "swiglu" | "clamped_swiglu" | "srelu";
+    x [R, 2H] (gated: [act | gate], or blocks of `interleave` act / gate columns) or [R, H]; scales [R];
+    grad [R, H] or None.  Returns (out [R, H], grad_input like x or None, grad_scales [R] or None), all fp32."""
+    f = np.float32
+    x = np.ascontiguousarray(x, f)
+    sc = np.ascontiguousarray(scales, f).reshape(-1, 1)
+    sig = lambda v: (f(1) / (f(1) + np.exp(-v, dtype=f))).astype(f)
+    gated = kind != "srelu"
+    R = x.shape[0]
+    if gated:
+        H = x.shape[1] // 2
+        if interleave > 0:                                  # test_scaled_activation.cu:46-59
+            blk = x.reshape(R, H // interleave, 2, interleave)
+            a, g = blk[:, :, 0, :].reshape(R, H), blk[:, :, 1, :].reshape(R, H)
+        else:
+            a, g = x[:, :H], x[:, H:]
+    else:
+        H = x.shape[1]
+        a, g = x, None
+    if kind == "swiglu":                                    # :64-70
+        s = sig(a)
+        act = a * s
+        unscaled = act * g
+        dact = (a * (s * (f(1) - s)) + s) * g
+        dlin = act
+    elif kind == "clamped_swiglu":                          # :71-82
+        lim, al = f(limit), f(alpha)
+        c = np.minimum(lim, a)
+        s = sig(al * c)
+        act = c * s
+        base = np.where(a <= lim, al * c * (s * (f(1) - s)) + s, f(0)).astype(f)
+        lin = np.minimum(np.maximum(-lim, g), lim) + f(offset)
+        unscaled = act * lin
+        dact = base * lin
+        dlin = np.where((g <= lim) & (g >= -lim), act, f(0)).astype(f)
+    else:                                                   # :83-88, test_common.h:530-531
+        unscaled = np.where(a > 0, a * a, f(0)).astype(f)
+        dact = np.maximum(f(0), f(2) * a)
+        dlin = None
+    out = (unscaled * sc).astype(f)
+    if grad is None:
+        return out, None, None
+    dy = np.ascontiguousarray(grad, f)
+    sg = dy * sc                                            # :116-118,122-123
+    da = sg * dact
+    if gated:
+        dg = sg * dlin
+        if interleave > 0:
+            dx = np.stack([da.reshape(R, H // interleave, interleave), dg.reshape(R, H // interleave, interleave)],
+                          axis=2).reshape(R, 2 * H)
+        else:
+            dx = np.concatenate([da, dg], axis=1)
+    else:
+        dx = da
+    dscales = np.sum((dy * unscaled).astype(np.float64), axis=1).astype(f)   # :127 (serial fp32 sum there)
+    return out, np.ascontiguousarray(dx, f), dscales
+
+
 def colsum(x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x)
     rows = int(np.prod(x.shape[:-1]))

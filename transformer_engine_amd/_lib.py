@@ -226,6 +226,12 @@ _SIGS = {
     "nvte_clamped_swiglu_v2": (_V, [_P, _P, _F, _F, _F, _P]),
     "nvte_clamped_dswiglu": (_V, [_P, _P, _P, _F, _F, _P]),
     "nvte_clamped_dswiglu_v2": (_V, [_P, _P, _P, _F, _F, _F, _P]),
+    "nvte_scaled_swiglu": (_V, [_P, _P, _P, C.c_int64, _P]),
+    "nvte_scaled_clamped_swiglu": (_V, [_P, _P, _P, _F, _F, _F, C.c_int64, _P]),
+    "nvte_scaled_dswiglu": (_V, [_P, _P, _P, _P, _P, C.c_int64, _P]),
+    "nvte_scaled_clamped_dswiglu": (_V, [_P, _P, _P, _P, _P, _F, _F, _F, C.c_int64, _P]),
+    "nvte_scaled_srelu": (_V, [_P, _P, _P, _P]),
+    "nvte_scaled_dsrelu": (_V, [_P, _P, _P, _P, _P, _P]),
     "nvte_dgelu": (_V, [_P, _P, _P, _P]),
     "nvte_dsilu": (_V, [_P, _P, _P, _P]),
     "nvte_drelu": (_V, [_P, _P, _P, _P]),

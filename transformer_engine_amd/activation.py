@@ -113,6 +113,74 @@ def clamped_dswiglu(grad: torch.Tensor, x: torch.Tensor, quantizer=None, *, limi
     return _finish(out, hp, quantizer)
 
 
+SCALED = ("swiglu", "clamped_swiglu", "srelu")
+
+
+def _flat2d(t: torch.Tensor) -> torch.Tensor:
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if t2.is_contiguous() else t2.contiguous()
+
+
+def scaled_activation(name: str, x: torch.Tensor, act_scales: torch.Tensor, *, glu_interleave_size: int = 0,
+                      limit: float = 7.0, alpha: float = 1.702, glu_linear_offset: float = 1.0,
+                      out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``Act(x) * act_scales[:, None]`` in one kernel (``nvte_scaled_swiglu`` / ``nvte_scaled_clamped_swiglu`` /
+    ``nvte_scaled_srelu``, ref activation.h:372-406,590-600 - what ``ops/basic/swiglu.py:_ScaledGLU`` and
+    ``ops/basic/activation.py:ScaledSReLU`` compute): the MoE expert activation times the router
+    probability of its token.  x [..., 2H] (gated; optionally in the block-interleaved layout) or [..., H]."""
+    assert name in SCALED, name
+    x2 = _flat2d(x)
+    gated = name != "srelu"
+    h = x2.shape[1] // 2 if gated else x2.shape[1]
+    out = torch.empty((x2.shape[0], h), dtype=out_dtype or x.dtype, device=x.device)
+    sc = act_scales.reshape(-1).contiguous()
+    wi, ws, wo = wrap_plain(x2), wrap_plain(sc), wrap_plain(out)
+    st = current_stream_ptr()
+    try:
+        if name == "swiglu":
+            api.nvte_scaled_swiglu(wi.handle, ws.handle, wo.handle, C.c_int64(glu_interleave_size), st)
+        elif name == "clamped_swiglu":
+            api.nvte_scaled_clamped_swiglu(wi.handle, ws.handle, wo.handle, C.c_float(limit), C.c_float(alpha),
+                                           C.c_float(glu_linear_offset), C.c_int64(glu_interleave_size), st)
+        else:
+            api.nvte_scaled_srelu(wi.handle, ws.handle, wo.handle, st)
+    finally:
+        wi.destroy(); ws.destroy(); wo.destroy()
+    return out.reshape(*x.shape[:-1], h)
+
+
+def scaled_dactivation(name: str, grad: torch.Tensor, x: torch.Tensor, act_scales: torch.Tensor, *,
+                       glu_interleave_size: int = 0, limit: float = 7.0, alpha: float = 1.702,
+                       glu_linear_offset: float = 1.0, with_scale_grad: bool = True,
+                       scale_grad_dtype: Optional[torch.dtype] = None):
+    """Backward of :func:`scaled_activation` (``nvte_scaled_dswiglu`` / ``nvte_scaled_clamped_dswiglu`` /
+    ``nvte_scaled_dsrelu``, ref activation.h:513-552,602-615).  Returns (grad_input with x's shape,
+    grad_act_scales [rows] or None)."""
+    assert name in SCALED, name
+    x2, g2 = _flat2d(x), _flat2d(grad)
+    dx = torch.empty_like(x2)
+    sc = act_scales.reshape(-1).contiguous()
+    dsc = torch.empty(x2.shape[0], dtype=scale_grad_dtype or x.dtype, device=x.device) if with_scale_grad else None
+    wg, wi, ws, wo = wrap_plain(g2), wrap_plain(x2), wrap_plain(sc), wrap_plain(dx)
+    wd = wrap_plain(dsc) if dsc is not None else None
+    hd = wd.handle if wd is not None else None
+    st = current_stream_ptr()
+    try:
+        if name == "swiglu":
+            api.nvte_scaled_dswiglu(wg.handle, wi.handle, ws.handle, wo.handle, hd, C.c_int64(glu_interleave_size), st)
+        elif name == "clamped_swiglu":
+            api.nvte_scaled_clamped_dswiglu(wg.handle, wi.handle, ws.handle, wo.handle, hd, C.c_float(limit),
+                                            C.c_float(alpha), C.c_float(glu_linear_offset),
+                                            C.c_int64(glu_interleave_size), st)
+        else:
+            api.nvte_scaled_dsrelu(wg.handle, wi.handle, ws.handle, wo.handle, hd, st)
+    finally:
+        wg.destroy(); wi.destroy(); ws.destroy(); wo.destroy()
+        if wd is not None:
+            wd.destroy()
+    return dx.reshape(x.shape), dsc
+
+
 def dbias_dact(name: str, grad: torch.Tensor, act_input: torch.Tensor, quantizer: Float8Quantizer):
     """tex.dbias_d<name>(grad, act_input, quantizer) -> (dbias, quantized grad * act'(act_input))."""
     if name not in UNARY:

@@ -211,6 +211,25 @@ __device__ __forceinline__ float block_max(float v, float *scratch) {
   return v;
 }
 
+// Wave sum on the DPP path (cross-lane operands of ordinary vector adds) instead of six dependent
+// ds_bpermute round trips through the LDS crossbar: quad swaps, two row rotations, then the row totals
+// travel down the rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lane 63 ends
+// up with the total of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0xb1, 0xf>(v);   // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4e, 0xf>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0x124, 0xf>(v);  // row_ror:4
+  v = dpp_add<0x128, 0xf>(v);  // row_ror:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 // amax values are >= 0, so their fp32 bit patterns order like unsigned ints
 // (ref common/utils.cuh:935: int-punned atomicMax).  The target only ever grows during a
 // launch, so a relaxed device-scope read that already shows a value >= v makes the atomic

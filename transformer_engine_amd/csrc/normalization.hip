@@ -58,25 +58,6 @@ enum : int { kZE4M3 = 0, kZE5M2 = 1, kZSame = 2 };  // output kind of the vector
 // The barrier is the bare instruction behind a wait for this wave's LDS traffic only: __syncthreads()
 // also waits for every outstanding global load and store of the wave (one counter on gfx9), which
 // would drain the next row's prefetch and the previous row's stores at every reduction.
-// Wave sum on the DPP path (cross-lane operands of ordinary vector adds) instead of six dependent
-// ds_bpermute round trips through the LDS crossbar: quad swaps, two row rotations, then the row totals
-// travel down the rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Lane 63 ends
-// up with the total of all 64 lanes.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0xb1, 0xf>(v);   // quad_perm:[1,0,3,2]
-  v = dpp_add<0x4e, 0xf>(v);   // quad_perm:[2,3,0,1]
-  v = dpp_add<0x124, 0xf>(v);  // row_ror:4
-  v = dpp_add<0x128, 0xf>(v);  // row_ror:8
-  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
-  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
-  return v;
-}
-
 template <int NW = 4>
 __device__ __forceinline__ void block_sum2(float &a, float &b, float (*red)[NW][2], unsigned &phase) {
   a = wave_sum_to_lane63(a);
