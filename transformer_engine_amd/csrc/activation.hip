@@ -425,15 +425,17 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a_i
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
         v[o][k] = ok ? v[o][k] : 0.f;
-        amax = fmaxf(amax, __builtin_fabsf(v[o][k]));
+        if constexpr (!FP8) amax = fmaxf(amax, __builtin_fabsf(v[o][k]));   // FP8: folded into quantize8 below
       }
       if constexpr (DBIAS) cs[k] += v[0][k];
     }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
       if constexpr (FP8) {
-        q[o][i][0] = pack4<OK>(v[o][0] * scale, v[o][1] * scale, v[o][2] * scale, v[o][3] * scale);
-        q[o][i][1] = pack4<OK>(v[o][4] * scale, v[o][5] * scale, v[o][6] * scale, v[o][7] * scale);
+        // amax of the unscaled values and sat(v * scale); the clamp is decided once for the 8 values
+        const u32x2 w8 = quantize8<OK == kOutE4M3 ? Fp8::E4M3 : Fp8::E5M2>(v[o], scale, amax);
+        q[o][i][0] = w8[0];
+        q[o][i][1] = w8[1];
         if (ok && a.out_c) {
           u32x2 w = {q[o][i][0], q[o][i][1]};
           *reinterpret_cast<u32x2 *>(static_cast<uint8_t *>(a.out_c) + r * a.ld_out + o * a.cols + col0) = w;
