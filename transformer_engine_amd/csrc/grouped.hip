@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256) void group_cast_transpose_kernel(
       float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const bool ok = col_ok && row0 + i < rows;
       if (ok) Load8<IT>::run(src + (row0 + i) * cols + col0, f);
-      q[i][0] = cvt4_fp8<F>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
-      q[i][1] = cvt4_fp8<F>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+      float unused_amax = 0.f;   // the group's amaxes come from their own pass (current scaling)
+      const u32x2 w8 = quantize8<F>(f, scale, unused_amax);
+      q[i][0] = w8[0];
+      q[i][1] = w8[1];
       if (ok && dst_c) {
         u32x2 v = {q[i][0], q[i][1]};
         *reinterpret_cast<u32x2 *>(dst_c + (row0 + i) * cols + col0) = v;
@@ -264,8 +266,10 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
       mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
       const uint8_t e = float_to_e8m0(mx * rcp_max);
       const float r = e8m0_rcp(e);
-      u32x2 q = {cvt4_fp8<F>(f[i][0] * r, f[i][1] * r, f[i][2] * r, f[i][3] * r),
-                 cvt4_fp8<F>(f[i][4] * r, f[i][5] * r, f[i][6] * r, f[i][7] * r)};
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f[i][j] * r;
+      const u32x2 q = cvt8_fp8<F>(o, mx * r <= Fp8Traits<F>::max_finite);   // as mxfp8_tile_kernel
       if (live) *reinterpret_cast<u32x2 *>(dst + (row0 + i) * cols + col0) = q;
       uint32_t e32 = e;
       const uint32_t e1 = __shfl_down(e32, 4, 64);
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
   if constexpr (COL) {
     uint32_t qc[8][2];
     uint32_t ebytes[2] = {0u, 0u};
+    bool in_range = true;   // every one of this thread's 8 column blocks scales into the finite range
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float mx = 0.f;
@@ -293,13 +298,15 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
       const uint8_t e = float_to_e8m0(mx * rcp_max);
       ebytes[j >> 2] |= static_cast<uint32_t>(e) << (8 * (j & 3));
       const float r = e8m0_rcp(e);
+      in_range = in_range && (mx * r <= Fp8Traits<F>::max_finite);
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i][j] *= r;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      qc[i][0] = cvt4_fp8<F>(f[i][0], f[i][1], f[i][2], f[i][3]);
-      qc[i][1] = cvt4_fp8<F>(f[i][4], f[i][5], f[i][6], f[i][7]);
+      const u32x2 w8 = cvt8_fp8<F>(f[i], in_range);
+      qc[i][0] = w8[0];
+      qc[i][1] = w8[1];
       if constexpr (!TCOL) {
         u32x2 q = {qc[i][0], qc[i][1]};
         if (live) *reinterpret_cast<u32x2 *>(out_col + m.off + (row0 + i) * cols + col0) = q;

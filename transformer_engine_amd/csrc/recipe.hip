@@ -111,23 +111,54 @@ __global__ void scale_from_amax_kernel(const float *amax, float *scale, float ma
 enum class AmaxAlgo : int { MostRecent = 0, Max = 1 };
 
 // Roll one history column by -1, zero its head, return the reduction the algorithm asks
-// for (valid in every thread).  `last` is the value that moves to the tail.
-template <int BS>
+// for (valid in every thread).  `last_fn()` gives the value that moves to the tail, or 0 for "leave the
+// column alone" (bulk update: no amax was recorded); it is only evaluated AFTER the column's loads have been
+// issued, so the loads it depends on (the head of the column, the reduced amax) and the column itself are one
+// round trip to memory, not two - these kernels are a chain of dependent latencies, nothing else.
+template <int BS, typename LastFn>
 __device__ __forceinline__ float roll_column(const float *hist_in, float *hist_out, size_t length,
-                                             size_t stride, float last, AmaxAlgo algo,
-                                             float *red /* BS/64 floats */) {
+                                             size_t stride, LastFn last_fn, bool skip_if_zero, AmaxAlgo algo,
+                                             float *red /* BS/64 floats */, float &last_out) {
   float amax = 0.f;
-  for (size_t off = 0; off < length; off += BS) {
-    const size_t i = off + threadIdx.x;
-    float a = 0.f;
-    if (i < length) {
-      a = (i < length - 1) ? hist_in[(i + 1) * stride] : last;
-      amax = fmaxf(amax, a);
+  constexpr int kInRegs = 8;   // histories up to 8 * BS entries (the default length is 1024) roll through registers:
+  if (length <= static_cast<size_t>(kInRegs) * BS) {   // every load in flight at once, ONE barrier, then the stores
+    float a[kInRegs];
+#pragma unroll
+    for (int v = 0; v < kInRegs; ++v) {
+      const size_t i = static_cast<size_t>(v) * BS + threadIdx.x;
+      a[v] = (i + 1 < length) ? hist_in[(i + 1) * stride] : 0.f;
+    }
+    const float last = last_fn();
+    last_out = last;
+    if (skip_if_zero && last == 0.0f) return 0.f;   // uniform over the workgroup
+#pragma unroll
+    for (int v = 0; v < kInRegs; ++v) {
+      const size_t i = static_cast<size_t>(v) * BS + threadIdx.x;
+      if (i + 1 == length) a[v] = last;
+      if (i < length) amax = fmaxf(amax, a[v]);
     }
     __syncthreads();  // the roll may be in place
-    if (i < length) hist_out[i * stride] = (i > 0) ? a : 0.f;
+#pragma unroll
+    for (int v = 0; v < kInRegs; ++v) {
+      const size_t i = static_cast<size_t>(v) * BS + threadIdx.x;
+      if (i < length) hist_out[i * stride] = (i > 0) ? a[v] : 0.f;
+    }
+  } else {
+    const float last = last_fn();
+    last_out = last;
+    if (skip_if_zero && last == 0.0f) return 0.f;
+    for (size_t off = 0; off < length; off += BS) {
+      const size_t i = off + threadIdx.x;
+      float a = 0.f;
+      if (i < length) {
+        a = (i < length - 1) ? hist_in[(i + 1) * stride] : last;
+        amax = fmaxf(amax, a);
+      }
+      __syncthreads();  // the roll may be in place
+      if (i < length) hist_out[i * stride] = (i > 0) ? a : 0.f;
+    }
   }
-  if (algo == AmaxAlgo::MostRecent) return last;
+  if (algo == AmaxAlgo::MostRecent) return last_out;
   amax = wave_max(amax);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
@@ -152,10 +183,11 @@ __global__ __launch_bounds__(kDsThreads) void delayed_scaling_kernel(
     size_t stride, AmaxAlgo algo, float scaled_max) {
   __shared__ float red[kDsThreads / 64];
   const size_t col = blockIdx.x;
-  const float last = hist_in[col];
-  const float amax = roll_column<kDsThreads>(hist_in + col, hist_out + col, length, stride, last,
-                                             algo, red);
-  if (threadIdx.x == 0) scale_out[col] = updated_scale(amax, scale_in[col], scaled_max);
+  const float head = hist_in[col], old_scale = scale_in[col];
+  float last;
+  const float amax = roll_column<kDsThreads>(hist_in + col, hist_out + col, length, stride, [&] { return head; },
+                                             false, algo, red, last);
+  if (threadIdx.x == 0) scale_out[col] = updated_scale(amax, old_scale, scaled_max);
 }
 
 // One launch covers up to kBulk (history, scale) pairs; grid = (pairs, max num_scale).
@@ -177,18 +209,15 @@ __global__ __launch_bounds__(kDsThreads) void delayed_scaling_bulk_kernel(
   const int col = blockIdx.y;
   if (col >= ent.num_scale) return;  // uniform per block
   float *hist = ent.hist + col;
-  float last = hist[0];
-  if (reduced != nullptr) {
-    const float r = reduced[ent.buf_offset + col];
-    if (r != 0.0f) last = r;
-  }
-  float amax = 0.f;
-  if (last != 0.0f) {
-    amax = roll_column<kDsThreads>(hist, hist, length, ent.num_scale, last, algo, red);
-  } else if (algo == AmaxAlgo::MostRecent) {
-    amax = last;
-  }
-  if (threadIdx.x == 0) ent.scale[col] = updated_scale(amax, ent.scale[col], scaled_max);
+  // three independent loads up front (head of the column, the reduced amax, the scale to fall back on)
+  const float head = hist[0];
+  const float r = reduced != nullptr ? reduced[ent.buf_offset + col] : 0.0f;
+  const float old_scale = ent.scale[col];
+  float last;
+  // a column with no recorded amax (last == 0) is left alone, its reduction is 0 (-> the old scale stays)
+  const float amax = roll_column<kDsThreads>(hist, hist, length, ent.num_scale,
+                                             [&] { return r != 0.0f ? r : head; }, true, algo, red, last);
+  if (threadIdx.x == 0) ent.scale[col] = updated_scale(amax, old_scale, scaled_max);
 }
 
 AmaxAlgo parse_algo(const char *s) {
