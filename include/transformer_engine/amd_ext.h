@@ -57,6 +57,20 @@ int nvte_amd_get_columnwise_transposed(const NVTETensor tensor);
 void nvte_amd_set_grouped_columnwise_transposed(NVTEGroupedTensor tensor, int transposed);
 int nvte_amd_get_grouped_columnwise_transposed(const NVTEGroupedTensor tensor);
 
+/* A list of independent GEMMs in ONE persistent launch (no counterpart in the reference, whose list form
+ * nvte_multi_tensor_gemm, gemm/cublaslt_gemm.cu:1052, spreads the list over streams and shares one
+ * transa / transb): entry i computes D[i] = op(A[i]) op(B[i]) (+ D[i] when accumulate[i]) exactly as
+ * nvte_cublas_gemm(A[i], B[i], D[i], NULL, NULL, transa[i], transb[i], grad, workspace, accumulate[i], ...)
+ * does.  Meant for the dgrad + wgrad pair of a layer: the tiles of all entries form one list that the
+ * persistent workgroups walk, cut per XCD by cost, so a GEMM whose tile count is not a multiple of the
+ * workgroup count (wgrad of Llama-3-8B's FFN: 3.5 rounds) leaves no idle half round.  Taken when 2 <= num_gemms
+ * <= 8, every operand is FP8 with per-tensor scaling, the FP8 formats and the (high-precision) output dtype
+ * agree across the list and workspace holds nvte_get_grouped_gemm_setup_workspace_size(num_gemms) bytes;
+ * any other list runs as the nvte_cublas_gemm calls above, one after the other.  accumulate may be NULL. */
+void nvte_amd_multi_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor *D, const int *transa,
+                         const int *transb, int num_gemms, int grad, NVTETensor workspace, const int *accumulate,
+                         hipStream_t stream);
+
 /* Library identification: "transformerengine_amd <version> gfx950". */
 const char *nvte_amd_version(void);
 

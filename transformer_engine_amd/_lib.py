@@ -80,6 +80,7 @@ _SIGS = {
     "nvte_amd_last_error": (C.c_char_p, []),
     "nvte_amd_clear_error": (_V, []),
     "nvte_amd_version": (C.c_char_p, []),
+    "nvte_amd_multi_gemm": (_V, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "nvte_amd_set_columnwise_transposed": (_V, [_P, _I]),
     "nvte_amd_set_grouped_columnwise_transposed": (_V, [_P, _I]),
     "nvte_swizzle_grouped_scaling_factors": (_V, [_P, _P, _P]),

@@ -236,9 +236,26 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   const unsigned nk = (a.k + BK - 1) / BK;
   unsigned total_tiles = a.ntiles;
   unsigned grp = 0;  // GROUPED: member that holds the tile located last
+  // GROUPED: the global tile list is cut into 8 contiguous runs, one per XCD (workgroup id % 8), whose
+  // boundaries the setup kernel chose by COST (K tiles + epilogue per tile), not by count: members with a
+  // different K (dgrad + wgrad of one layer in one launch) then still finish together.  The table sits
+  // behind the tile prefix; run x is [xrun[x], xrun[x + 1]).
+  unsigned xrun[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto run_of = [&](unsigned flat, unsigned &pos) {   // flat workgroup-space index -> list position, valid?
+    const unsigned x = flat & 7u, loc = flat >> 3;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (x == static_cast<unsigned>(i)) { lo = xrun[i]; hi = xrun[i + 1]; }
+    pos = lo + loc;
+    return pos < hi;
+  };
   if constexpr (GROUPED) {
     total_tiles = a.group_tile_start[a.num_groups];
-    if (blockIdx.x >= total_tiles) return;  // whole workgroup, before any barrier
+#pragma unroll
+    for (int i = 0; i < 9; ++i) xrun[i] = a.group_tile_start[a.num_groups + 1 + i];
+    unsigned pos0;
+    if (!run_of(blockIdx.x, pos0)) return;  // whole workgroup, before any barrier
   }
 
   // MX: the scale buffer this wave stages (P's for waves 0-3, Q's for waves 4-7)
@@ -269,12 +286,12 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     TileCtx t;
     unsigned ti, tj;
     if constexpr (GROUPED) {
-      if (!valid) tile = 0;
       {
-        // same XCD-aware remap as tile_of: the workgroups of one XCD (id % 8) walk a contiguous run
-        // of the global tile list, so an XCD's L2 holds few P / Q panels at a time.
-        const unsigned q8 = total_tiles / 8, r8 = total_tiles % 8, xcd = tile % 8, loc = tile / 8;
-        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+        // XCD-aware as tile_of: the workgroups of one XCD (id % 8) walk a contiguous run of the global
+        // tile list, so an XCD's L2 holds few P / Q panels at a time.
+        unsigned pos;
+        run_of(tile, pos);
+        tile = valid ? pos : 0u;
       }
       // stateless member lookup (the member g with tile_start[g] <= tile < tile_start[g + 1]; empty
       // members have equal bounds and are skipped): with a grid that is not a multiple of 8 (a
@@ -675,7 +692,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     using Yes = std::true_type;
     if (full) {
       if (with_c) epilogue_as(t, dptr, Yes{}, Yes{}, No{});
-      else if (!GROUPED && a.nt_store) epilogue_as(t, dptr, No{}, Yes{}, Yes{});
+      else if (a.nt_store) epilogue_as(t, dptr, No{}, Yes{}, Yes{});
       else epilogue_as(t, dptr, No{}, Yes{}, No{});
     } else {
       with_c ? epilogue_as(t, dptr, Yes{}, No{}, No{}) : epilogue_as(t, dptr, No{}, No{}, No{});
@@ -804,7 +821,11 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   unsigned g = 0;
   while (true) {
     const unsigned next = tile + gridDim.x;
-    const bool has_next = next < total_tiles;
+    bool has_next = next < total_tiles;
+    if constexpr (GROUPED) {
+      unsigned pos;
+      has_next = run_of(next, pos);
+    }
     const TileCtx next_t = make_tile(next, has_next);
     // K tiles of THIS output tile: the launch's, or the member's (never fewer than two)
     const unsigned nk_t = GROUPED ? max((cur_t.k + BK - 1) / BK, 2u) : nk;
@@ -1199,6 +1220,94 @@ __device__ __forceinline__ void member_dims(const GroupShapes &g, unsigned i, in
   off = g.offsets ? g.offsets[i] : static_cast<int64_t>(i) * g.uniform_first * g.uniform_last;
 }
 
+// Tail of the setup kernels (one wave; lane l owns members [lo_i, hi_i), whose records it has just written):
+// the tile prefix tile_start[0..G] and, behind it, the 9 boundaries of the per-XCD runs of the global tile list.
+// A tile costs its K tiles (never fewer than the two the pipeline runs) + 2 for the epilogue; boundary x is
+// where the running cost passes x/8 of the total.  With one K for every member this is the equal-count split;
+// with a workgroup count that is not a multiple of 8 (a workgroup then changes XCD run from tile to tile) the
+// equal-count split is forced: it is the one for which "flat index < total" and "position inside its run" agree.
+__device__ __forceinline__ void finish_group_setup(const GroupDesc *descs, unsigned *tile_start, unsigned G,
+                                                   unsigned lo_i, unsigned hi_i, unsigned grid) {
+  const unsigned lane = threadIdx.x;
+  unsigned local = 0;
+  unsigned long long local_cost = 0;
+  for (unsigned i = lo_i; i < hi_i; ++i) {
+    const unsigned tiles = ((descs[i].n + BM - 1) / BM) * descs[i].tiles_j;
+    local += tiles;
+    local_cost += static_cast<unsigned long long>(tiles) * (max((descs[i].k + BK - 1) / BK, 2u) + 2u);
+  }
+  unsigned incl = local;
+  unsigned long long incl_cost = local_cost;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(incl, off, 64);
+    const unsigned long long upc = __shfl_up(incl_cost, off, 64);
+    if (lane >= static_cast<unsigned>(off)) {
+      incl += up;
+      incl_cost += upc;
+    }
+  }
+  const unsigned total = __shfl(incl, 63, 64);
+  const unsigned long long total_cost = __shfl(incl_cost, 63, 64);
+  unsigned run = incl - local;
+  for (unsigned i = lo_i; i < hi_i; ++i) {
+    tile_start[i] = run;
+    run += ((descs[i].n + BM - 1) / BM) * descs[i].tiles_j;
+  }
+  unsigned *xrun = tile_start + G + 1;
+  if (lane == 63) {
+    tile_start[G] = total;
+    xrun[0] = 0;
+    xrun[8] = total;
+  }
+  if (grid % 8 != 0 || total_cost == 0) {
+    if (lane >= 1 && lane < 8) {
+      const unsigned q8 = total / 8, r8 = total % 8;
+      xrun[lane] = lane < r8 ? lane * (q8 + 1) : r8 * (q8 + 1) + (lane - r8) * q8;
+    }
+    return;
+  }
+  // the lane whose members straddle a boundary's cost knows where that boundary ideally falls ...
+  unsigned ideal[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) ideal[x] = 0xFFFFFFFFu;
+  unsigned long long cost_run = incl_cost - local_cost;
+  unsigned tile_run = incl - local;
+  for (unsigned i = lo_i; i < hi_i; ++i) {
+    const unsigned tiles = ((descs[i].n + BM - 1) / BM) * descs[i].tiles_j;
+    const unsigned long long c = max((descs[i].k + BK - 1) / BK, 2u) + 2u;
+    const unsigned long long end = cost_run + tiles * c;
+#pragma unroll
+    for (unsigned x = 1; x < 8; ++x) {
+      const unsigned long long target = total_cost * x / 8;
+      if (tiles != 0 && target >= cost_run && target < end)
+        ideal[x] = tile_run + static_cast<unsigned>((target - cost_run + c / 2) / c);
+    }
+    cost_run = end;
+    tile_run += tiles;
+  }
+  // ... every lane learns all seven (wave minimum: exactly one lane holds each), and lane 0 snaps the run
+  // LENGTHS to whole rounds of the XCD's grid / 8 workgroups: a run of 129 tiles costs its 32 workgroups five
+  // rounds, one of 128 four (the last run takes what the rounding leaves)
+#pragma unroll
+  for (int x = 1; x < 8; ++x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ideal[x] = min(ideal[x], static_cast<unsigned>(__shfl_xor(ideal[x], off, 64)));
+  }
+  if (lane == 0) {
+    const unsigned wpx = grid / 8;
+    unsigned prev = 0;
+#pragma unroll
+    for (int x = 1; x < 8; ++x) {
+      const unsigned want = min(max(ideal[x], prev), total);
+      unsigned b = prev + (want - prev + wpx / 2) / wpx * wpx;
+      b = min(b, total);
+      xrun[x] = b;
+      prev = b;
+    }
+  }
+}
+
 // One wave: lane l builds the records of members [l * per, (l + 1) * per) and the tile prefix.
 __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, unsigned *tile_start,
                                                            const GroupedOperandMeta A, const GroupedOperandMeta B,
@@ -1206,7 +1315,8 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
                                                            const ListedInputs la, const ListedOutputs lo,
                                                            const float *alpha, int alpha_n, const float *beta,
                                                            int beta_n, unsigned G, int transa, int transb,
-                                                           unsigned d_elem_bytes, int has_c, GroupScaleDesc *sdescs) {
+                                                           unsigned d_elem_bytes, int has_c, GroupScaleDesc *sdescs,
+                                                           unsigned grid) {
   const unsigned lane = threadIdx.x;
   const unsigned per = (G + 63) / 64, lo_i = lane * per, hi_i = min(lo_i + per, G);
   const bool mx = sdescs != nullptr;
@@ -1240,7 +1350,6 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     a_sc_run = a_incl - a_loc;
     b_sc_run = b_incl - b_loc;
   }
-  unsigned local = 0;
   for (unsigned i = lo_i; i < hi_i; ++i) {
     int64_t a_first, a_last, a_off = 0, b_first, b_last, b_off, d_first, d_last, d_off = 0;
     const uint8_t *q_ptr;
@@ -1301,26 +1410,14 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     d.beta = has_c ? beta[beta_n > 1 ? i : 0] : 0.f;
     d.tiles_j = (d.m + BN - 1) / BN;
     descs[i] = d;
-    local += ((d.n + BM - 1) / BM) * d.tiles_j;
   }
-  unsigned incl = local;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned up = __shfl_up(incl, off, 64);
-    if (lane >= static_cast<unsigned>(off)) incl += up;
-  }
-  unsigned run = incl - local;
-  for (unsigned i = lo_i; i < hi_i; ++i) {
-    tile_start[i] = run;
-    run += ((descs[i].n + BM - 1) / BM) * descs[i].tiles_j;
-  }
-  if (lane == 63) tile_start[G] = incl;
+  finish_group_setup(descs, tile_start, G, lo_i, hi_i, grid);
 }
 
-// records | tile prefix | MXFP8 scale records (+ 256 to align the caller's pointer)
+// records | tile prefix + the 9 XCD run boundaries | MXFP8 scale records (+ 256 to align the caller's pointer)
+size_t group_prefix_bytes(size_t G) { return round_up((G + 1 + 9) * sizeof(unsigned), 256); }
 size_t grouped_setup_bytes(size_t G) {
-  return round_up(G * sizeof(GroupDesc), 256) + round_up((G + 1) * sizeof(unsigned), 256) +
-         round_up(G * sizeof(GroupScaleDesc), 256) + 256;
+  return round_up(G * sizeof(GroupDesc), 256) + group_prefix_bytes(G) + round_up(G * sizeof(GroupScaleDesc), 256) + 256;
 }
 
 // Pick the K-contiguous storage of an FP8 grouped operand ("TN everywhere", like the ungrouped path
@@ -1478,15 +1575,20 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   GroupDesc *descs = reinterpret_cast<GroupDesc *>(ws_al);
   unsigned *tile_start = reinterpret_cast<unsigned *>(ws_al + round_up(G * sizeof(GroupDesc), 256));
   GroupScaleDesc *sdescs = mx ? reinterpret_cast<GroupScaleDesc *>(ws_al + round_up(G * sizeof(GroupDesc), 256) +
-                                                                   round_up((G + 1) * sizeof(unsigned), 256))
+                                                                   group_prefix_bytes(G))
                               : nullptr;
 
   const DeviceInfo &di = device_info();
+  unsigned cus = static_cast<unsigned>(di.num_cus);
+  if (config != nullptr) {
+    const int want = static_cast<const GroupedMatmulConfig *>(config)->sm_count;
+    if (want > 0) cus = std::min(cus, static_cast<unsigned>(want));
+  }
   hipLaunchKernelGGL(grouped_setup_kernel, dim3(1), dim3(64), 0, stream, descs, tile_start, A, B, C, D, la, lo,
                      static_cast<const float *>(alpha.data.ptr), static_cast<int>(alpha.data.numel()),
                      static_cast<const float *>(beta.data.ptr), static_cast<int>(beta.data.numel()),
                      static_cast<unsigned>(G), transa ? 1 : 0, transb ? 1 : 0,
-                     static_cast<unsigned>(dtype_bits(d_dtype) / 8), has_c, sdescs);
+                     static_cast<unsigned>(dtype_bits(d_dtype) / 8), has_c, sdescs, cus);
   NVTE_CHECK_HIP(hipGetLastError());
 
   GemmArgs g;
@@ -1498,17 +1600,129 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   g.group_tile_start = tile_start;
   g.num_groups = static_cast<unsigned>(G);
   g.d_dtype = d_dtype;
-  unsigned cus = static_cast<unsigned>(di.num_cus);
-  if (config != nullptr) {
-    const int want = static_cast<const GroupedMatmulConfig *>(config)->sm_count;
-    if (want > 0) cus = std::min(cus, static_cast<unsigned>(want));
-  }
   g.grid = cus;  // persistent: the tile count is only known on the device
   (void)api;
   if (mx)
     launch_by_format<true, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
   else
     launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
+}
+
+// ---- nvte_amd_multi_gemm (amd_ext.h): a LIST of independent GEMMs in one persistent launch --------------
+// dgrad and wgrad of one layer are independent and read the same dY; launched one after the other, wgrad's
+// 896 tiles leave half the chip idle for its last half round (3.5 rounds of 256 workgroups).  As two members of
+// one grouped launch the 512 + 896 tiles are 5.5 rounds: the cost-weighted XCD runs of finish_group_setup give
+// every XCD the same number of K tiles although the two members have a different K.
+constexpr int kMaxMulti = 8;
+struct MultiEntry {
+  const uint8_t *P, *Q;
+  const float *sP, *sQ;
+  void *D;
+  unsigned n, m, k;
+  float beta;
+};
+struct MultiParams {
+  MultiEntry e[kMaxMulti];
+};
+__global__ __launch_bounds__(64) void multi_setup_kernel(GroupDesc *descs, unsigned *tile_start, const MultiParams p,
+                                                         unsigned G, unsigned grid) {
+  const unsigned lane = threadIdx.x;
+  if (lane < G) {
+    const MultiEntry &e = p.e[lane];
+    GroupDesc d;
+    d.P = e.P;
+    d.Q = e.Q;
+    d.D = e.D;
+    d.C = e.beta != 0.f ? e.D : nullptr;
+    d.mult = *e.sP * *e.sQ;
+    d.beta = e.beta;
+    d.n = e.n;
+    d.m = e.m;
+    d.k = e.k;
+    d.tiles_j = (e.m + BN - 1) / BN;
+    descs[lane] = d;
+  }
+  finish_group_setup(descs, tile_start, G, min(lane, G), min(lane + 1, G), grid);
+}
+
+// the K-contiguous FP8 storage of a per-tensor-scaled operand ("TN everywhere", as gemm_impl)
+bool pick_tensor_scaling_operand(const Tensor &T, bool use_rowwise, Operand &op) {
+  if (!is_tensor_scaling(T.scaling_mode)) return false;
+  if (use_rowwise) {
+    if (!T.has_data()) return false;
+    op.data = static_cast<const uint8_t *>(T.data.ptr);
+    op.dtype = T.data.dtype;
+    op.scale_inv = T.scale_inv.ptr;
+  } else {
+    if (!T.has_columnwise_data()) return false;
+    op.data = static_cast<const uint8_t *>(T.columnwise_data.ptr);
+    op.dtype = T.columnwise_data.dtype;
+    op.scale_inv = T.columnwise_scale_inv.ptr;
+  }
+  return is_fp8(op.dtype) && op.data != nullptr && op.scale_inv != nullptr &&
+         (reinterpret_cast<uintptr_t>(op.data) & 15u) == 0;
+}
+
+void multi_gemm_impl(const NVTETensor *A, const NVTETensor *B, NVTETensor *D, const int *transa, const int *transb,
+                     int num, bool grad, const Tensor *workspace, const int *accumulate, hipStream_t stream) {
+  NVTE_CHECK(num >= 0, "nvte_amd_multi_gemm: negative num_gemms");
+  NVTE_CHECK(num == 0 || (A && B && D && transa && transb), "nvte_amd_multi_gemm: null argument list");
+  // one launch when every GEMM is a plain per-tensor-scaled FP8 GEMM of the same formats and output dtype;
+  // otherwise (and for a single GEMM) the list runs as nvte_cublas_gemm calls, one after the other
+  MultiParams p;
+  std::memset(&p, 0, sizeof(p));
+  bool fuse = num >= 2 && num <= kMaxMulti && workspace != nullptr && workspace->data.ptr != nullptr;
+  int fp = -1, fq = -1;
+  DType d_dtype = kNVTEFloat32;
+  size_t min_out_bytes = ~static_cast<size_t>(0);
+  for (int i = 0; fuse && i < num; ++i) {
+    const Tensor &a = *lookup_checked(A[i]);
+    const Tensor &b = *lookup_checked(B[i]);
+    const Tensor &d = *lookup_checked(D[i]);
+    const auto [A0, A1] = a.flat2d();
+    const auto [B0, B1] = b.flat2d();
+    const size_t m = transa[i] ? A0 : A1, k = transa[i] ? A1 : A0, n = transb[i] ? B1 : B0;
+    Operand opA, opB;
+    fuse = (transb[i] ? B0 : B1) == k && m > 0 && n > 0 && k >= 16 && k % 16 == 0 && k <= (1u << 23) &&
+           n < (1ull << 31) && m < (1ull << 31) && pick_tensor_scaling_operand(a, transa[i] != 0, opA) &&
+           pick_tensor_scaling_operand(b, transb[i] == 0, opB) && d.data.ptr != nullptr && d.data.numel() == m * n &&
+           is_high_precision(d.data.dtype);
+    if (!fuse) break;
+    if (i == 0) {
+      fp = fmt_of(opB.dtype);
+      fq = fmt_of(opA.dtype);
+      d_dtype = d.data.dtype;
+    }
+    fuse = fp == fmt_of(opB.dtype) && fq == fmt_of(opA.dtype) && d_dtype == d.data.dtype;
+    p.e[i] = MultiEntry{opB.data, opA.data, static_cast<const float *>(opB.scale_inv),
+                        static_cast<const float *>(opA.scale_inv), d.data.ptr, static_cast<unsigned>(n),
+                        static_cast<unsigned>(m), static_cast<unsigned>(k), (accumulate && accumulate[i]) ? 1.f : 0.f};
+    min_out_bytes = std::min(min_out_bytes, m * n * dtype_bits(d.data.dtype) / 8);
+  }
+  const size_t ws_bytes = workspace ? workspace->data.numel() * dtype_bits(workspace->data.dtype) / 8 : 0;
+  fuse = fuse && ws_bytes >= grouped_setup_bytes(static_cast<size_t>(num));
+  if (!fuse) {
+    for (int i = 0; i < num; ++i)
+      gemm_impl(*lookup_checked(A[i]), *lookup_checked(B[i]), *lookup_checked(D[i]), nullptr, nullptr, transa[i] != 0,
+                transb[i] != 0, grad, workspace, 1.f, (accumulate && accumulate[i]) ? 1.f : 0.f, stream);
+    return;
+  }
+  const size_t G = static_cast<size_t>(num);
+  const uintptr_t ws_al = (reinterpret_cast<uintptr_t>(workspace->data.ptr) + 255) & ~static_cast<uintptr_t>(255);
+  GroupDesc *descs = reinterpret_cast<GroupDesc *>(ws_al);
+  unsigned *tile_start = reinterpret_cast<unsigned *>(ws_al + round_up(G * sizeof(GroupDesc), 256));
+  const unsigned cus = static_cast<unsigned>(device_info().num_cus);
+  hipLaunchKernelGGL(multi_setup_kernel, dim3(1), dim3(64), 0, stream, descs, tile_start, p, static_cast<unsigned>(G), cus);
+  NVTE_CHECK_HIP(hipGetLastError());
+  GemmArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.groups = descs;
+  g.group_tile_start = tile_start;
+  g.num_groups = static_cast<unsigned>(G);
+  g.d_dtype = d_dtype;
+  g.grid = cus;
+  g.nt_store = min_out_bytes > kNtStoreBytes ? 1u : 0u;   // as gemm_impl: outputs nobody re-reads from cache
+  launch_by_format<false, false, true>(fp, fq, g, stream);
 }
 
 // ---- static scratch for nvte_amd_grouped_gemm_noalloc (amd_ext.h) --------------------------------
@@ -1585,6 +1799,14 @@ void nvte_amd_grouped_gemm_noalloc(const NVTEGroupedTensor A, int transa, const 
     // prefix entry of this call's G members before the GEMM kernel (same stream) reads them.
     grouped_gemm_impl("nvte_amd_grouped_gemm_noalloc", call, G, transa != 0, transb != 0, alpha, beta,
                       scratch_ptr(), kNoAllocScratchBytes, config, stream);
+  });
+}
+
+void nvte_amd_multi_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor *D, const int *transa,
+                         const int *transb, int num_gemms, int grad, NVTETensor workspace, const int *accumulate,
+                         hipStream_t stream) {
+  api_guard("nvte_amd_multi_gemm", [&] {
+    multi_gemm_impl(A, B, D, transa, transb, num_gemms, grad != 0, lookup(workspace), accumulate, stream);
   });
 }
 

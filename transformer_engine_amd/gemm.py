@@ -169,6 +169,51 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
     return _finish(hp_out), bias_grad, gelu_input, extra_output
 
 
+def multi_gemm(entries, grad: bool = False):
+    """A list of independent FP8 GEMMs in ONE persistent launch (``nvte_amd_multi_gemm``, amd_ext.h): each entry
+    is ``(A, B, layout, out_or_dtype, accumulate)`` with the meaning of the same :func:`general_gemm` call
+    (no bias, no GELU, high-precision output).  The library fuses the list when every operand is per-tensor
+    scaled FP8 of matching formats and the outputs share a dtype (the dgrad + wgrad pair of a layer), and runs
+    it entry by entry otherwise - the results are those of the separate calls either way."""
+    if not entries:
+        return []
+    dev = entries[0][0].device
+    n = len(entries)
+    was, wbs, wds, outs = [], [], [], []
+    ta, tb, acc = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+    wws = None
+    try:
+        for i, (A, B, layout, out, accumulate) in enumerate(entries):
+            assert layout in ("TN", "NN", "NT"), f"GEMM layout {layout} not supported."
+            transa, transb = layout[0] == "T", layout[1] == "T"
+            wa, a_shape = _wrap_operand(A)
+            wb, b_shape = _wrap_operand(B)
+            was.append(wa); wbs.append(wb)
+            if _numel(a_shape) == 0 or _numel(b_shape) == 0:
+                raise ValueError("multi_gemm does not take empty operands: use general_gemm")
+            out_shape = gemm_output_shape(a_shape, b_shape, transa, transb)
+            if isinstance(out, torch.Tensor):
+                if out.numel() != _numel(out_shape) or not out.is_contiguous():
+                    raise ValueError(f"GEMM output has invalid dims (expected {out_shape}, got {tuple(out.shape)})")
+                o = out
+            else:
+                if accumulate:
+                    raise ValueError("accumulate=True needs an `out` tensor")
+                o = torch.empty(out_shape, dtype=out or torch.bfloat16, device=dev)
+            outs.append(o)
+            wds.append(wrap_plain(o))
+            ta[i], tb[i], acc[i] = int(transa), int(transb), int(bool(accumulate))
+        ha = (C.c_void_p * n)(*[w.handle for w in was])
+        hb = (C.c_void_p * n)(*[w.handle for w in wbs])
+        hd = (C.c_void_p * n)(*[w.handle for w in wds])
+        wws = wrap_plain(get_workspace(dev))
+        api.nvte_amd_multi_gemm(ha, hb, hd, ta, tb, n, int(grad), wws.handle, acc, current_stream_ptr())
+    finally:
+        for w in was + wbs + wds + ([wws] if wws is not None else []):
+            w.destroy()
+    return outs
+
+
 _WORKSPACES = {}
 
 

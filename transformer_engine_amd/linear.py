@@ -21,7 +21,7 @@ from typing import List, Optional
 import torch
 
 from ._lib import api
-from .gemm import general_gemm
+from .gemm import general_gemm, multi_gemm
 from .recipe import (DelayedScaling, DelayedScalingRecipeState, Float8CurrentScaling,
                      MXFP8BlockScaling, get_fp8_te_dtype, reduce_and_update_fp8_tensors)
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor,
@@ -126,7 +126,7 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
 def linear_backward(dy: torch.Tensor, saved, st: LinearFP8State, *, use_bias: bool = False,
                     wgrad_out: Optional[torch.Tensor] = None, accumulate_wgrad: bool = False,
                     grad_dtype: Optional[torch.dtype] = None, requires_dgrad: bool = True,
-                    requires_wgrad: bool = True):
+                    requires_wgrad: bool = True, fuse_bwd_gemms: bool = False):
     """Returns (dx, dw, dbias)."""
     x8, w8 = saved
     qg = st.bwd_q[BWD_GRAD_OUTPUT]
@@ -142,6 +142,16 @@ def linear_backward(dy: torch.Tensor, saved, st: LinearFP8State, *, use_bias: bo
             dbias = dy2d.sum(dim=0)
     gdt = grad_dtype or dy.dtype
     dx = dw = None
+    if (fuse_bwd_gemms and requires_dgrad and requires_wgrad and isinstance(dy8, Float8Tensor)
+            and isinstance(w8, Float8Tensor) and isinstance(x8, Float8Tensor)
+            and (wgrad_out is None or wgrad_out.dtype == gdt)):
+        # dgrad (linear.py:1062) and wgrad (linear.py:1225-1261) are independent: one persistent launch for
+        # both (amd_ext.h nvte_amd_multi_gemm), bit-equal to the two calls.  Off by default: it saves a launch
+        # and the gap behind it in eager mode (-32 us on configs[1]) but measured 0.7 % slower inside a replayed
+        # HIP graph, where wgrad's half-empty last round costs little (the idle CUs leave the others more clock).
+        dx, dw = multi_gemm([(w8, dy8, "NN", gdt, False),
+                             (x8, dy8, "NT", wgrad_out if wgrad_out is not None else gdt, accumulate_wgrad)], grad=True)
+        return dx, dw, dbias
     if requires_dgrad:
         dx, *_ = general_gemm(w8, dy8, out_dtype=gdt, layout="NN", grad=True)          # linear.py:1062
     if requires_wgrad:
