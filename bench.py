@@ -416,6 +416,15 @@ def main():
         t_dgrad = time_kernel(lambda: general_gemm(w8, dy8, layout="NN", out=dx, grad=True), it)
         t_wgrad = time_kernel(lambda: general_gemm(x8, dy8, layout="NT", out=dw, grad=True), it)
         gemm_flops = 2.0 * M * N * K
+        # the same fprop launch on operands whose bits do not toggle (all zeros): what the kernel's instruction
+        # stream sustains when the chip does not drop its clock under switching power - the GEMM on random
+        # operand bits is power-bound, and this figure separates that from the kernel's own stalls
+        from transformer_engine_amd.tensor import Float8CurrentScalingQuantizer
+        qz = Float8CurrentScalingQuantizer(qi.dtype, dev)
+        x8z, w8z = qz(torch.zeros_like(x)), qz(torch.zeros_like(w))
+        t_fprop_zero = time_kernel(lambda: general_gemm(w8z, x8z, layout="TN", out=y), it)
+        t_fprop_again = time_kernel(lambda: general_gemm(w8, x8, layout="TN", out=y), it)
+        del x8z, w8z
         # ---- the same kernels timed INSIDE the step: args.steps eager steps of the timed workload with a
         # HIP event pair (on the launch stream) around every hot launch.  These are the durations the
         # roofline uses - they include the cache state a real step leaves behind (a kernel launched
@@ -517,6 +526,13 @@ def main():
             "cast_transpose_GBps": {"x": x.numel() * 4 / t_ct_x / 1e6, "w": w.numel() * 4 / t_ct_w / 1e6,
                                     "dy": dy.numel() * 4 / t_ct_dy / 1e6},
             "gemm_only_tflops": 3 * gemm_flops / ((t_fprop + t_dgrad + t_wgrad) * 1e-3) / 1e12,
+            "power_bound_check": {
+                "fprop_ms_random_operands": t_fprop_again, "fprop_ms_zero_operands": t_fprop_zero,
+                "tflops_random": gemm_flops / t_fprop_again / 1e9, "tflops_zero": gemm_flops / t_fprop_zero / 1e9,
+                "frac_of_peak_zero_operands": gemm_flops / t_fprop_zero / 1e9 / PEAK_FP8_TFLOPS,
+                "note": "same kernel, same shapes, same launch: only the operand bits differ (all-zero FP8 payloads "
+                        "vs the workload's randn data); the difference is the clock the chip gives up under "
+                        "switching power, not kernel stalls"},
             "weight_quantize_ms_not_in_step": t_ct_w,
         }
         if not args.no_grouped and world == 1:
