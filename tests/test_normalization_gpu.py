@@ -241,3 +241,31 @@ def test_zero_centered_gamma_in_weight_dtype_switch(N, H, kind):
     rdx_w, _, _ = oracle.norm_backward(to_oracle_input(dz), to_oracle_input(x), mu_np, rs.cpu().numpy(),
                                        to_oracle_input(g_rounded))
     assert np.allclose(w_dx, rdx_w, rtol=8e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("N", [1, 3, 257])
+@pytest.mark.parametrize("H", [4096, 12288, 1000])
+def test_norm_few_rows(N, H):
+    """Fewer rows than persistent workgroups (most workgroups exit at once, the others never prefetch a second
+    row), and a row count that leaves the last round of workgroups ragged; vector (full / guarded) and scalar paths."""
+    x, g, b = _inputs(N, H, torch.bfloat16, 41)
+    dz = randn_input((N, H), torch.bfloat16, 42)
+    out, mu, rs = layernorm_fwd(x, g, b, 1e-5)
+    dx, dg, db = layernorm_bwd(dz, x, mu, rs, g)
+    q = Float8Quantizer(torch.full((1,), 4.0, device="cuda"), torch.zeros(1, device="cuda"), E4, columnwise=False)
+    out8, _, rs8 = rmsnorm_fwd(x, g, 1e-5, quantizer=q)
+    torch.cuda.synchronize()
+    ref, rmu, rrs, _ = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g), to_oracle_input(b), 1e-5)
+    assert np.allclose(out.float().cpu().numpy(), ref, rtol=8e-3, atol=1e-5)
+    assert np.allclose(mu.cpu().numpy(), rmu, rtol=5e-5, atol=1e-6) and np.allclose(rs.cpu().numpy(), rrs, rtol=5e-5, atol=1e-6)
+    rdx, rdg, rdb = oracle.norm_backward(to_oracle_input(dz), to_oracle_input(x), mu.cpu().numpy(), rs.cpu().numpy(),
+                                         to_oracle_input(g))
+    tol = 2 ** -7
+    assert np.allclose(dx.float().cpu().numpy(), rdx, rtol=tol, atol=tol)
+    assert np.allclose(dg.float().cpu().numpy(), rdg, rtol=tol, atol=tol * (np.abs(rdg).max() + 1.0))
+    assert np.allclose(db.float().cpu().numpy(), rdb, rtol=tol, atol=tol * (np.abs(rdb).max() + 1.0))
+    ref8, _, _, ramax = oracle.norm_forward(to_oracle_input(x), to_oracle_input(g), None, 1e-5, scale=4.0)
+    got = oracle.fp8_to_float(u8(out8._data), oracle.E4M3)
+    want = oracle.fp8_to_float(oracle.float_to_fp8(ref8, oracle.E4M3), oracle.E4M3)
+    assert (np.abs(got - want) <= np.maximum(2.0 ** -3 * np.abs(want) + 2.0 ** -9, 1e-2 + 1e-2 * np.abs(want))).all()
+    assert np.isclose(q.amax.item(), ramax, rtol=1e-5)
