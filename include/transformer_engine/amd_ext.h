@@ -21,6 +21,11 @@ int nvte_amd_get_error_mode(void);
  * nvte_* call on the same thread. */
 const char *nvte_amd_last_error(void);
 void nvte_amd_clear_error(void);
+/* Address of a process-wide count of recorded errors (all threads).  A foreign-function binding reads it
+ * before and after a call - a plain memory read - and only asks for nvte_amd_last_error() when it moved:
+ * polling the thread-local slot through a second foreign call after EVERY call doubled the per-call cost of
+ * the ctypes binding. */
+const unsigned long long *nvte_amd_error_counter(void);
 
 /* Plain-C twin of nvte_delayed_scaling_recipe_amax_and_scale_update_after_reduction
  * (ref recipe.h:71-74, whose std::vector arguments make the symbol C++-mangled). */

@@ -41,13 +41,23 @@ class NVTETensorPack(C.Structure):
     _fields_ = [("tensors", C.c_void_p * 10), ("size", C.c_size_t)]
 
 
+_SHAPES = {}
+
+
 def make_shape(dims: Sequence[int]) -> NVTEShape:
-    s = NVTEShape()
-    if len(dims) > 15:
-        raise ValueError("NVTEShape holds at most 15 dims")
-    for i, d in enumerate(dims):
-        s.data[i] = int(d)
-    s.ndim = len(dims)
+    """NVTEShape of `dims`.  The same few shapes recur every step: the structs are built once and reused (the
+    library copies them, and no caller here writes into one)."""
+    key = tuple(dims)
+    s = _SHAPES.get(key)
+    if s is None:
+        if len(key) > 15:
+            raise ValueError("NVTEShape holds at most 15 dims")
+        s = NVTEShape()
+        for i, d in enumerate(key):
+            s.data[i] = int(d)
+        s.ndim = len(key)
+        if len(_SHAPES) < 4096:
+            _SHAPES[key] = s
     return s
 
 
@@ -79,6 +89,7 @@ _SIGS = {
     "nvte_amd_get_error_mode": (_I, []),
     "nvte_amd_last_error": (C.c_char_p, []),
     "nvte_amd_clear_error": (_V, []),
+    "nvte_amd_error_counter": (C.POINTER(C.c_ulonglong), []),
     "nvte_amd_version": (C.c_char_p, []),
     "nvte_amd_multi_gemm": (_V, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "nvte_amd_set_columnwise_transposed": (_V, [_P, _I]),
@@ -297,6 +308,7 @@ class _Api:
         lib.nvte_amd_set_error_mode(1)
         self._last_error = lib.nvte_amd_last_error
         self._clear_error = lib.nvte_amd_clear_error
+        self._errors = lib.nvte_amd_error_counter()      # process-wide count of recorded errors
         self._cache = {}
 
     def __getattr__(self, name):
@@ -305,14 +317,16 @@ class _Api:
         fn = self._cache.get(name)
         if fn is None:
             raw = getattr(self._lib, name)
-            last_error, clear_error = self._last_error, self._clear_error
+            last_error, clear_error, errors = self._last_error, self._clear_error, self._errors
 
             def fn(*a, _raw=raw):
+                before = errors[0]
                 r = _raw(*a)
-                e = last_error()
-                if e is not None:
-                    clear_error()
-                    raise NVTEError(e.decode("utf-8", "replace"))
+                if errors[0] != before:          # some thread recorded an error during the call: ours?
+                    e = last_error()
+                    if e is not None:
+                        clear_error()
+                        raise NVTEError(e.decode("utf-8", "replace"))
                 return r
 
             fn.__name__ = name

@@ -298,9 +298,11 @@ thread_local bool tl_has_error = false;
 }  // namespace
 
 int error_mode() { return g_error_mode.load(std::memory_order_relaxed); }
+std::atomic<unsigned long long> g_error_count{0};   // every recorded error, any thread (see nvte_amd_error_counter)
 void record_error(const char *api, const char *what) {
   tl_error = std::string(api) + ": " + what;
   tl_has_error = true;
+  g_error_count.fetch_add(1, std::memory_order_relaxed);
 }
 void api_enter(const char *) { tl_has_error = false; }
 
@@ -364,6 +366,9 @@ extern "C" {
 void nvte_amd_set_error_mode(int mode) { g_error_mode.store(mode ? 1 : 0); }
 int nvte_amd_get_error_mode(void) { return g_error_mode.load(); }
 const char *nvte_amd_last_error(void) { return tl_has_error ? tl_error.c_str() : nullptr; }
+const unsigned long long *nvte_amd_error_counter(void) {
+  return reinterpret_cast<const unsigned long long *>(&te::g_error_count);
+}
 void nvte_amd_clear_error(void) { tl_has_error = false; }
 const char *nvte_amd_version(void) { return "transformerengine_amd 0.1 gfx950"; }
 
