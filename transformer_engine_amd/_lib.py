@@ -331,6 +331,7 @@ class _Api:
 
             fn.__name__ = name
             self._cache[name] = fn
+            setattr(self, name, fn)     # later accesses find the attribute and skip __getattr__
         return fn
 
 

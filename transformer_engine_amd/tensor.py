@@ -176,9 +176,43 @@ class _CachedWrapper(TensorWrapper):
             pass
 
 
+_PLAIN = {}          # (data_ptr, dtype, shape) -> handle: a descriptor of that memory, whoever owns it now
+_PLAIN_MAX = 512
+
+
 def wrap_plain(t: torch.Tensor) -> TensorWrapper:
-    """High-precision (or raw byte) tensor -> handle with only rowwise data."""
-    return TensorWrapper().set_rowwise_data(t)
+    """High-precision (or raw byte) tensor -> handle with only rowwise data.  The handle only says "this
+    dtype and shape at this address", so it is kept and handed out again for the same triple (the caching
+    allocator returns the same blocks step after step): three foreign calls per wrap otherwise, a dozen wraps
+    per Linear step.  The cache itself holds no reference to the tensor (the object returned does, for as long
+    as the caller keeps it), and callers never modify the handles they get here."""
+    if not t.is_contiguous():
+        raise ValueError("NVTETensor buffers must be contiguous")
+    key = (t.data_ptr(), t.dtype, tuple(t.shape))
+    w = _PLAIN.get(key)
+    if w is None:
+        if len(_PLAIN) >= _PLAIN_MAX:
+            _PLAIN.pop(next(iter(_PLAIN)))
+        w = _CachedWrapper()
+        w._set(_lib.kRowwiseData, key[0], te_dtype(t.dtype), key[2])
+        _PLAIN[key] = w
+    return _PlainRef(w, t)
+
+
+class _PlainRef:
+    """What wrap_plain hands out: the shared handle plus a reference to the tensor, so that a temporary
+    (``wrap_plain(x.contiguous())``) lives as long as the caller holds this object, as it did when every wrap
+    built its own handle."""
+    __slots__ = ("handle", "_w", "_t")
+
+    def __init__(self, w, t):
+        self.handle, self._w, self._t = w.handle, w, t
+
+    def destroy(self):
+        self._t = None
+
+    def __getattr__(self, name):          # getters of the underlying wrapper (shape(), get_param(), ...)
+        return getattr(self._w, name)
 
 
 class QuantizationConfig:
