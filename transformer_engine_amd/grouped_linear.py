@@ -32,7 +32,11 @@ class GroupedLinearFP8State:
                                                           amax_epsilon=recipe.amax_epsilon)
         elif isinstance(recipe, MXFP8BlockScaling):
             # member rows (m_splits) must be multiples of 128; columnwise copies per member, transposed (amd_ext.h)
-            mk = lambda dt: MXFP8Quantizer(dt, columnwise_transposed=True)
+            # scales in the layout the grouped GEMM reads (ref module/grouped_linear.py:349, :864, :1905)
+            def mk(dt):
+                q = MXFP8Quantizer(dt, columnwise_transposed=True)
+                q.optimize_for_gemm = True
+                return q
         else:
             raise NotImplementedError("the grouped path implements FP8 current scaling and MXFP8")
         self.q_input, self.q_weight, self.q_grad = mk(f), mk(f), mk(b)

@@ -66,7 +66,9 @@ def bgrad_quantize(dy: torch.Tensor, quantizer):
 class LinearFP8State:
     """Per-module quantization state: recipe states + quantizers for one Linear."""
 
-    def __init__(self, recipe, device=None):
+    def __init__(self, recipe, device=None, compact_mx_scales=()):
+        """compact_mx_scales: which of "input", "weight", "grad_output" keep their MXFP8 scales in the compact
+        layout (the others are written GEMM-swizzled, see below)."""
         self.recipe = recipe
         self.device = device or torch.device("cuda")
         self.fwd_state: Optional[DelayedScalingRecipeState] = None
@@ -88,6 +90,13 @@ class LinearFP8State:
             # columnwise copies in the K-contiguous (transposed) layout the dgrad / wgrad GEMMs read
             self.fwd_q = [MXFP8Quantizer(f, columnwise_transposed=True) for _ in range(3)]
             self.bwd_q = [MXFP8Quantizer(b, columnwise_transposed=True) for _ in range(2)]
+            # Scales are written in the layout the GEMM reads (ref module/linear.py:2067-2078 for the input and
+            # grad_output quantizers, module/base.py:1211-1229 for the weight), except where another consumer needs
+            # the compact one: an all-gather of the operand (column+SP input, row+SP grad_output, same rule as
+            # the reference) or the norm kernel that writes the MXFP8 input itself (rmsnorm_api.cpp:32 / ln_api.cpp:36 check).
+            for name, q in (("input", self.fwd_q[FWD_INPUT]), ("weight", self.fwd_q[FWD_WEIGHT]),
+                            ("grad_output", self.bwd_q[BWD_GRAD_OUTPUT])):
+                q.optimize_for_gemm = name not in compact_mx_scales
         else:
             raise TypeError(f"unsupported recipe {type(recipe)}")
         self.weight_cache = None  # quantized weight kept across microbatches
@@ -174,6 +183,8 @@ def layernorm_linear_forward(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: 
     from .normalization import layernorm_fwd, rmsnorm_fwd
     qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
     qi.set_usage(rowwise=True, columnwise=needs_backward)
+    if isinstance(qi, MXFP8Quantizer):
+        qi.optimize_for_gemm = False       # the norm kernels write compact scales only (ref ln_api.cpp:36)
     x2d = x.reshape(-1, x.shape[-1])
     if normalization == "LayerNorm":
         ln8, mu, rsigma = layernorm_fwd(x2d, ln_weight, ln_bias, eps, quantizer=qi,
@@ -309,7 +320,8 @@ class LayerNormLinear(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.empty(out_features, in_features, dtype=params_dtype, device=device))
         torch.nn.init.normal_(self.weight, std=0.02)
         self.bias = torch.nn.Parameter(torch.zeros(out_features, dtype=params_dtype, device=device)) if bias else None
-        self.fp8_state = LinearFP8State(recipe or DelayedScaling(), device=torch.device(device))
+        self.fp8_state = LinearFP8State(recipe or DelayedScaling(), device=torch.device(device),
+                                        compact_mx_scales=("input",))   # the norm kernel writes the MXFP8 input
         self._is_first_microbatch = None
         self.amax_group = None
 
