@@ -121,6 +121,29 @@ def grouped_c5(dev, iters):
             "m_splits": m_splits, "ms_per_step": ms, "tflops": 6.0 * M * N * K / (ms * 1e-3) / 1e12}
 
 
+def mxfp8_c3(dev, iters):
+    """Side measurement (not `value`): BASELINE configs[2]-shaped MXFP8 Linear step on ONE GPU - 8192 tokens,
+    8192 -> 8192, MXFP8 block scaling (scales written GEMM-swizzled, the module default), fwd+bwd, weight cached."""
+    from transformer_engine_amd import linear as L
+    from transformer_engine_amd.recipe import MXFP8BlockScaling
+    M = K = N = 8192
+    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
+    st = L.LinearFP8State(MXFP8BlockScaling(), device=dev)
+    L.linear_forward(x, w, None, st, is_first_microbatch=True)
+
+    def step():
+        y, saved = L.linear_forward(x, w, None, st, is_first_microbatch=False)
+        L.linear_backward(dy, saved, st)
+
+    for _ in range(5):      # allocator and clocks settled before the timed loop
+        step()
+    ms = time_kernel(step, iters)
+    return {"workload": "Linear 8192->8192, 8192 tokens, MXFP8 block scaling, fwd+bwd, eager, 1 GPU",
+            "ms_per_step": ms, "tflops": 6.0 * M * N * K / (ms * 1e-3) / 1e12}
+
+
 def cpu_baseline(tokens=4096, K=4096, N=14336):
     """The reference's CPU path (tests/cpp host references, restated in oracle/) on a bounded
     sample of the SAME workload: the configs[1] Linear (4096 -> 14336, full-size weight) forward +
@@ -537,6 +560,7 @@ def main():
         }
         if not args.no_grouped and world == 1:
             result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
+            result["extra"]["c3_mxfp8_linear"] = mxfp8_c3(dev, max(5, args.steps // 4))
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
             # configs[0] (the reference's CPU-runnable case: Linear 768 -> 3072, 2048 tokens) in full, CPU and GPU

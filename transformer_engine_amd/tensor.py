@@ -571,18 +571,21 @@ class MXFP8Quantizer(Quantizer):
     def make_empty(self, shape, *, dtype=torch.float32, device=None) -> MXFP8Tensor:
         device = device or torch.device("cuda")
         rs, cs = self.scale_shapes(shape)
+        rows, cols = _flat2d(tuple(shape))
+        # the padding of the scale matrices reads as zero (ref mxfp8_tensor.py make_empty); whole 128 x 128 tiles
+        # have none, every scale byte is then written by the quantize kernel and the two fill launches are saved
+        scales = torch.empty if (rows % 128 == 0 and cols % 128 == 0) else torch.zeros
         rd = rsi = cd = csi = None
         if self.rowwise_usage:
             rd = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
-            rsi = torch.zeros(rs, dtype=torch.uint8, device=device)
+            rsi = scales(rs, dtype=torch.uint8, device=device)
         if self.columnwise_usage:
             if self.columnwise_transposed:
-                rows, cols = _flat2d(tuple(shape))
                 cd = torch.empty((cols, rows), dtype=torch.uint8, device=device)
-                csi = torch.zeros((cs[1], cs[0]), dtype=torch.uint8, device=device)
+                csi = scales((cs[1], cs[0]), dtype=torch.uint8, device=device)
             else:
                 cd = torch.empty(tuple(shape), dtype=torch.uint8, device=device)
-                csi = torch.zeros(cs, dtype=torch.uint8, device=device)
+                csi = scales(cs, dtype=torch.uint8, device=device)
         return MXFP8Tensor(shape=shape, dtype=dtype, rowwise_data=rd, rowwise_scale_inv=rsi,
                            columnwise_data=cd, columnwise_scale_inv=csi, fp8_dtype=self.dtype,
                            quantizer=self, with_gemm_swizzled_scales=self.optimize_for_gemm,
