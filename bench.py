@@ -525,6 +525,10 @@ def main():
         result["roofline"]["timing"] = "HIP events around each launch inside args.steps eager steps of the timed workload"
         result["roofline"]["launch_ms_min_median_max"] = {k: [s[0], s[len(s) // 2], s[-1]] for k, s in samples.items()}
         result["roofline"]["stalled_pairs_dropped"] = {k: len(samples[k]) - len(kept[k]) for k in samples}
+        # cross-check against the timed region itself: the medians of the instrumented launches add up to the
+        # replayed step (see extra.step_breakdown), the means carry the eager loop's occasional +20 % launches
+        med = [samples[k][len(samples[k]) // 2] for k in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")]
+        result["roofline"]["frac_at_median_launch"] = gemm_flops / (sum(med) / 3.0 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS
         result["roofline_cast_transpose"]["launch_ms"] = step_ms["cast_transpose_dy"]
         # headline both ways: `value` amortises the weight quantize as te.Linear does with
         # is_first_microbatch=False; the other figure charges one full weight cast_transpose to every step
