@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256) void fused_act_tile_kernel(const FusedArgs a_i
     if (a.grp.num_tensors != 0) {
       // grouped: which member, which of its tiles; then everything below sees ONE member
       unsigned mem, lt;
-      if (!locate_tile(a.grp, blockIdx.x, mem, lt)) return;
-      const Member m = member_of(a.grp, mem);
+      Member m;
+      if (!locate_tile(a.grp, blockIdx.x, mem, lt, m)) return;
       const size_t off = static_cast<size_t>(m.off), row_base = off / a.cols;
       const size_t out_esz = (FP8 || MXO) ? 1 : (a.out_dtype == kNVTEFloat32 ? 4 : 2);
       tile_r = lt / tiles_c;

@@ -47,6 +47,36 @@ constexpr int kGroupTile = 128;
 // Which member and which of its 128x128 tiles does workgroup `b` own?  256 threads x 4 members:
 // tile counts -> block-wide exclusive scan -> the owner announces itself through LDS.
 // Returns false when b is past the last tile (the host sizes the grid from an upper bound).
+// Up to 64 members (every MoE layer in practice): each wave finds the owner by itself - lane t reads member
+// t's shape, a wave scan gives the tile prefix, a ballot the owner, and the owner's shape comes back through
+// a lane read instead of a second, dependent round of loads.  No LDS, no barrier in front of the first data load.
+__device__ __forceinline__ bool locate_tile_wave(const GroupShapes &g, unsigned b, unsigned &member, unsigned &local,
+                                                 Member &m) {
+  const unsigned lane = threadIdx.x & 63u;
+  Member mine{0, 0, 0};
+  unsigned c = 0;
+  if (lane < g.num_tensors) {
+    mine = member_of(g, lane);
+    c = static_cast<unsigned>(((mine.rows + kGroupTile - 1) / kGroupTile) * ((mine.cols + kGroupTile - 1) / kGroupTile));
+  }
+  unsigned incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(incl, off, 64);
+    if (lane >= static_cast<unsigned>(off)) incl += up;
+  }
+  const unsigned excl = incl - c;
+  const unsigned long long owners = __ballot(c > 0 && b >= excl && b < incl);
+  if (owners == 0ull) return false;
+  const int src = __ffsll(static_cast<long long>(owners)) - 1;
+  member = static_cast<unsigned>(src);
+  local = b - __shfl(excl, src, 64);
+  m.off = __shfl(mine.off, src, 64);
+  m.rows = __shfl(mine.rows, src, 64);
+  m.cols = __shfl(mine.cols, src, 64);
+  return true;
+}
+
 __device__ __forceinline__ bool locate_tile(const GroupShapes &g, unsigned b, unsigned &member, unsigned &local) {
   __shared__ unsigned wave_sum[4];
   __shared__ unsigned found[2];
@@ -86,6 +116,15 @@ __device__ __forceinline__ bool locate_tile(const GroupShapes &g, unsigned b, un
   member = found[0];
   local = found[1];
   return member != 0xFFFFFFFFu;
+}
+
+// Member and tile of workgroup b, with the member's shape: the wave form up to 64 members, the block scan beyond
+__device__ __forceinline__ bool locate_tile(const GroupShapes &g, unsigned b, unsigned &member, unsigned &local,
+                                            Member &m) {
+  if (g.num_tensors <= 64u) return locate_tile_wave(g, b, member, local, m);
+  if (!locate_tile(g, b, member, local)) return false;
+  m = member_of(g, member);
+  return true;
 }
 
 }  // namespace

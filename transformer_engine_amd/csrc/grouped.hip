@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void group_cast_transpose_kernel(
   if (noop_set(noop)) return;
   __shared__ __attribute__((aligned(16))) uint8_t tile_t[kTile * kTile];
   unsigned mem, lt;
-  if (!locate_tile(g, blockIdx.x, mem, lt)) return;
-  const Member m = member_of(g, mem);
+  Member m;
+  if (!locate_tile(g, blockIdx.x, mem, lt, m)) return;
   const size_t rows = static_cast<size_t>(m.rows), cols = static_cast<size_t>(m.cols);
   const unsigned tiles_c = static_cast<unsigned>((cols + kTile - 1) / kTile);
   const size_t tile_r = lt / tiles_c, tile_col = lt % tiles_c;
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
   __shared__ __attribute__((aligned(16))) uint8_t tile_t[TCOL ? kTile * kTile : 16];
   constexpr float rcp_max = 1.0f / Fp8Traits<F>::max_finite;
   unsigned mem, lt;
-  if (!locate_tile(g, blockIdx.x, mem, lt)) return;
-  const Member m = member_of(g, mem);
+  Member m;
+  if (!locate_tile(g, blockIdx.x, mem, lt, m)) return;
   const size_t rows = static_cast<size_t>(m.rows), cols = static_cast<size_t>(m.cols);
   const unsigned tiles_c = static_cast<unsigned>(cols / kTile);
   const size_t tile_r = lt / tiles_c, tile_col = lt % tiles_c;
