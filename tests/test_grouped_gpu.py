@@ -76,6 +76,8 @@ SPLITS = [
     ([48, 0, 208, 16, 1008], 384),   # rows % 16 == 0: vector path with partial tiles, one empty member
     ([5, 33, 1, 130], 72),           # odd rows: element path for the transposes
     ([7, 19], 100),                  # cols % 8 != 0: element path everywhere
+    ([16, 0, 48, 144, 32, 0, 16, 160] * 8, 128),    # 64 members: the largest group the per-wave member lookup takes
+    ([16, 0, 48, 144, 32] * 16, 128),               # 80 members: the block-scan lookup (group_lookup.h)
 ]
 
 
@@ -88,7 +90,7 @@ def test_group_quantize_current_scaling_varying_first_dim(splits, cols, in_dtype
     # very different magnitudes per member, so that a scale applied to the wrong member shows
     r0 = 0
     for i, s in enumerate(splits):
-        x[r0:r0 + s] *= 4.0 ** (i - 1)
+        x[r0:r0 + s] *= 4.0 ** (i % 5 - 1)
         r0 += s
     q = Float8CurrentScalingQuantizer(fmt, torch.device("cuda"))
     g = group_quantize(x, q, len(splits), first_dims=_dev_i64(splits))
