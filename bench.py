@@ -453,7 +453,8 @@ def main():
         # roofline uses - they include the cache state a real step leaves behind (a kernel launched
         # back to back on the same operands finds part of them in the 256 MiB Infinity Cache) and they
         # are what `rocprofv3 --kernel-trace --stats -- python3 bench.py` averages (profiles/).
-        in_step = {k: [] for k in ("cast_transpose_x", "gemm_fprop", "cast_transpose_dy", "gemm_dgrad", "gemm_wgrad")}
+        in_step = {k: [] for k in ("cast_transpose_x", "gemm_fprop", "cast_transpose_dy", "gemm_dgrad", "gemm_wgrad",
+                                   "empty_pair")}
 
         class rec:
             def __init__(self, role):
@@ -485,6 +486,8 @@ def main():
                 general_gemm(st.weight_cache, sdy8, layout="NN", grad=True, out=dx)
             with rec("gemm_wgrad"):
                 general_gemm(sx8, sdy8, layout="NT", grad=True, out=dw)
+            with rec("empty_pair"):      # two records with nothing between them: what a pair adds to any kernel
+                pass
             st.update_bwd()
 
         for _ in range(3):
@@ -525,6 +528,7 @@ def main():
         result["roofline"]["timing"] = "HIP events around each launch inside args.steps eager steps of the timed workload"
         result["roofline"]["launch_ms_min_median_max"] = {k: [s[0], s[len(s) // 2], s[-1]] for k, s in samples.items()}
         result["roofline"]["stalled_pairs_dropped"] = {k: len(samples[k]) - len(kept[k]) for k in samples}
+        result["roofline"]["event_pair_floor_ms"] = step_ms["empty_pair"]    # included in every launch_ms above, not subtracted
         # cross-check against the timed region itself: the medians of the instrumented launches add up to the
         # replayed step (see extra.step_breakdown), the means carry the eager loop's occasional +20 % launches
         med = [samples[k][len(samples[k]) // 2] for k in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")]
