@@ -94,6 +94,29 @@ def test_group_quantize_mxfp8_bit_exact(splits, swizzled, fmt, ofmt):
             r0 += m
 
 
+def test_group_quantize_mxfp8_member_rows_off_the_128_contract_stay_inside_the_member():
+    """Members whose rows are multiples of 32 but not of 128 take the kernel's guarded tile body (grouped.hip):
+    every whole 32-row block is still quantized bit-exactly and nothing of the neighbour is touched."""
+    splits, K = [160, 96], 256
+    x = _inputs(splits, K, 9)
+    fd = torch.tensor(splits, dtype=torch.int64, device="cuda")
+    q = MXFP8Quantizer(E4, rowwise=True, columnwise=True, columnwise_transposed=False)
+    out = group_quantize(x, q, len(splits), first_dims=fd)
+    torch.cuda.synchronize()
+    M = sum(splits)
+    row_all, col_all = _u8(out.rowwise_data).reshape(M, K), _u8(out.columnwise_data).reshape(M, K)
+    sc_row_all = _u8(out.scale_inv).reshape(-1, K // 32)
+    sc_col_all = _u8(out.columnwise_scale_inv).reshape(-1, K)
+    r0 = 0
+    for m in splits:
+        ref = oracle.mxfp8(_bits(x[r0:r0 + m]), oracle.E4M3)
+        assert np.array_equal(row_all[r0:r0 + m], ref["out_row"])
+        assert np.array_equal(sc_row_all[r0:r0 + m], ref["sc_row"][:m, :K // 32])
+        assert np.array_equal(col_all[r0:r0 + m], ref["out_col"])
+        assert np.array_equal(sc_col_all[r0 // 32:(r0 + m) // 32], ref["sc_col"][: m // 32, :K])
+        r0 += m
+
+
 def test_group_quantize_mxfp8_uniform_members_equals_single_tensor_quantize():
     """Same-shape members: the grouped launch writes exactly what MXFP8Quantizer writes for the stacked tensor
     (rowwise) and for each member (transposed columnwise)."""

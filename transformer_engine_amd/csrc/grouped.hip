@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <limits>
+#include <type_traits>
 
 #include "common.h"
 #include "device_utils.h"
@@ -241,8 +242,16 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
 
   const unsigned t = threadIdx.x, cg = t & 15u, rg = t >> 4, w = t >> 6;
   const size_t row0 = tile_r * kTile + rg * 8, col0 = tile_col * kTile + cg * 8;
-  const bool live = tile_r * kTile + (w + 1) * 32 <= rows;  // wave-uniform: this wave's 32-row block exists
   const IT *src = in + m.off;
+
+  // Two copies of the tile body: members that keep the 128-row contract (every valid call) run without the
+  // per-wave row guards - with them the eight loads sit behind a branch and the kernel loses 9-17 % (245 vs
+  // 204-216 us on [16384, 14336]; the single-tensor kernel: 203) - the guarded copy only keeps a member
+  // that breaks the contract inside its own rows.  (The same split of group_cast_transpose_kernel into
+  // whole and partial tiles was measured and gained nothing: 131 vs 127 us.)
+  auto body = [&](auto guard_tag) {
+  constexpr bool GUARD = decltype(guard_tag)::value;
+  const bool live = !GUARD || tile_r * kTile + (w + 1) * 32 <= rows;  // wave-uniform: this wave's 32-row block exists
 
   float f[8][8];
 #pragma unroll
@@ -313,9 +322,13 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
       }
     }
     if constexpr (TCOL) {
-      const size_t rows_left = rows - tile_r * kTile;
-      store_tile_transposed<true>(tile_t, qc, t, out_col + m.off + (tile_col * kTile) * rows + tile_r * kTile, rows,
-                                  static_cast<unsigned>(rows_left >= kTile ? 8 : rows_left / 32 * 2), kTile);
+      if constexpr (GUARD) {
+        const size_t rows_left = rows - tile_r * kTile;
+        store_tile_transposed<true>(tile_t, qc, t, out_col + m.off + (tile_col * kTile) * rows + tile_r * kTile, rows,
+                                    static_cast<unsigned>(rows_left >= kTile ? 8 : rows_left / 32 * 2), kTile);
+      } else {
+        store_tile_transposed(tile_t, qc, t, out_col + m.off + (tile_col * kTile) * rows + tile_r * kTile, rows);
+      }
     }
     if (live && (t & 63u) < 16u) {  // rg_local == 0 holds the wave's 32-row block scale for 8 columns
       if constexpr (TCOL) {
@@ -342,6 +355,8 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
       }
     }
   }
+  };  // body
+  if (rows % kTile == 0) body(std::false_type{}); else body(std::true_type{});
 }
 
 // ---------------------------------------------------------------- grouped dequantize / bias add
