@@ -65,10 +65,14 @@ __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
     const size_t col0 = static_cast<size_t>(tile % tiles_c) * kTile + cg * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (!GUARD || (col0 < cols && row0 + i < rows))
+      if constexpr (GUARD) {
+        // out-of-range lanes load a valid (clamped) address and the value is dropped at use: a bounds branch
+        // in front of the loads keeps them from being issued together
+        const size_t r = row0 + i < rows ? row0 + i : rows - 1, c = col0 < cols ? col0 : 0;
+        raw[i] = Raw8<IT>::load(in + r * cols + c);
+      } else {
         raw[i] = Raw8<IT>::load(in + (row0 + i) * cols + col0);
-      else
-        raw[i] = Raw8<IT>::zero();
+      }
     }
   };
 
@@ -95,6 +99,12 @@ __global__ __launch_bounds__(kCtThreads) void cast_transpose_tile_kernel(
     for (int i = 0; i < 8; ++i) {
       float f[8];
       cur[i].widen8(f);
+      if constexpr (GUARD) {
+        if (!(col0 < cols && row0 + i < rows)) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = 0.f;
+        }
+      }
       const u32x2 w = quantize8<F>(f, scale, amax);   // amax of the unscaled values, sat(f * scale)
       q[i][0] = w[0];
       q[i][1] = w[1];
