@@ -332,11 +332,14 @@ void launch_general_by_out(const Tensor &in, const float *noop, Tensor &out, boo
 
 // Workgroups per CU of the persistent tile kernel (LDS: 32 KiB each; more resident workgroups = more
 // loads in flight, fewer = longer-lived workgroups).  NVTE_AMD_CT_WGS_PER_CU overrides (tuning aid).
+// 3, not the 4 that fit: inside the configs[1] step X [8192, 4096] (2048 tiles) takes 28 us at 2 or 3 and
+// 35 us at 4, where every workgroup owns exactly two tiles and all of them move through load / store in step;
+// dY [8192, 14336] is the same 78 us from 2 to 6 (scratch/run_ct_instep.sh).
 unsigned ct_grid(size_t ntiles) {
   static const unsigned per_cu = [] {
     const char *e = std::getenv("NVTE_AMD_CT_WGS_PER_CU");
     const int v = e ? std::atoi(e) : 0;
-    return static_cast<unsigned>(v >= 1 && v <= 16 ? v : 4);
+    return static_cast<unsigned>(v >= 1 && v <= 16 ? v : 3);
   }();
   return static_cast<unsigned>(std::min<size_t>(ntiles, static_cast<size_t>(device_info().num_cus) * per_cu));
 }
