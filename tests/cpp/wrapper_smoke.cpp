@@ -6,6 +6,7 @@
 // quantizes, dequantizes and multiplies small-integer matrices and checks them exactly ("GPU OK").
 #include <transformer_engine/cast.h>
 #include <transformer_engine/gemm.h>
+#include <transformer_engine/recipe.h>
 #include <transformer_engine/runtime.h>
 #include <transformer_engine/transformer_engine.h>
 #include <transformer_engine/transpose.h>
@@ -145,6 +146,43 @@ int main() {
       for (size_t k = 0; k < K; ++k) ref += xf[i * K + k] * wf[j * K + k];
       REQUIRE(got_y[i * N + j] == ref);                                                              // exact: small integers
     }
+  // ---------------- the C++-signature recipe entry point (std::vector by value, mangled symbol; ref recipe.h:71-74,
+  // delayed_scaling.cu:162-253), called as pytorch/csrc/extensions/recipe.cpp does: packed reduction buffer,
+  // one [H, S] history and one [S] scale per layer.  Values are powers of two, so the expectations are exact.
+  {
+    //                     layer A: H = 4, S = 2                       layer B: H = 4, S = 1
+    const float histA[8] = {0.f, 0.f, 2.f, 1.f, 4.f, 0.5f, 1.f, 8.f}, histB[4] = {0.f, 32.f, 0.25f, 64.f};
+    const float scaleA[2] = {5.f, 3.f}, scaleB[1] = {9.f};
+    const float reduced[3] = {16.f, 0.f, 7.f};   // A/0 has a new amax, A/1 none (entry 0: no roll), B/0 = 7
+    float *dhA, *dhB, *dsA, *dsB, *dred;
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dhA), sizeof(histA))); HIP_OK(hipMalloc(reinterpret_cast<void **>(&dhB), sizeof(histB)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dsA), sizeof(scaleA))); HIP_OK(hipMalloc(reinterpret_cast<void **>(&dsB), sizeof(scaleB)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&dred), sizeof(reduced)));
+    HIP_OK(hipMemcpy(dhA, histA, sizeof(histA), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dhB, histB, sizeof(histB), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dsA, scaleA, sizeof(scaleA), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(dsB, scaleB, sizeof(scaleB), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dred, reduced, sizeof(reduced), hipMemcpyHostToDevice));
+    try {
+      TensorWrapper thA(dhA, std::vector<size_t>{4, 2}, DType::kFloat32), thB(dhB, std::vector<size_t>{4, 1}, DType::kFloat32);
+      TensorWrapper tsA(dsA, std::vector<size_t>{2}, DType::kFloat32), tsB(dsB, std::vector<size_t>{1}, DType::kFloat32);
+      TensorWrapper tred(dred, std::vector<size_t>{3}, DType::kFloat32);
+      nvte_delayed_scaling_recipe_amax_and_scale_update_after_reduction(
+          tred.data(), std::vector<NVTETensor>{thA.data(), thB.data()}, std::vector<NVTETensor>{tsA.data(), tsB.data()},
+          "max", static_cast<NVTEDType>(DType::kFloat8E4M3), 0.f, stream);
+      HIP_OK(hipStreamSynchronize(stream));
+    } catch (const std::exception &e) {
+      std::fprintf(stderr, "exception: %s\n", e.what());
+      return 1;
+    }
+    float gA[8], gB[4], gsA[2], gsB[1];
+    HIP_OK(hipMemcpy(gA, dhA, sizeof(gA), hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(gB, dhB, sizeof(gB), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(gsA, dsA, sizeof(gsA), hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(gsB, dsB, sizeof(gsB), hipMemcpyDeviceToHost));
+    // A/0: last = 16, amax = max(2, 4, 1, 16) = 16 -> scale 448 / 16, history rolled {0, 4, 1, 16}
+    REQUIRE(gsA[0] == 28.f && gA[0] == 0.f && gA[2] == 4.f && gA[4] == 1.f && gA[6] == 16.f);
+    // A/1: reduced entry 0 and history row 0 is 0 -> no roll, amax 0 -> the scale stays
+    REQUIRE(gsA[1] == 3.f && gA[1] == 0.f && gA[3] == 1.f && gA[5] == 0.5f && gA[7] == 8.f);
+    // B/0: last = 7, amax = max(32, 0.25, 64, 7) = 64 -> scale 7, history {0, 0.25, 64, 7}
+    REQUIRE(gsB[0] == 7.f && gB[0] == 0.f && gB[1] == 0.25f && gB[2] == 64.f && gB[3] == 7.f);
+  }
   std::puts("GPU OK");
   return 0;
 }

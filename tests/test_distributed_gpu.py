@@ -211,16 +211,12 @@ def _run(case, recipe_name, overlap):
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("recipe_name", ["delayed", "current", "mxfp8"])
 def test_column_parallel_sp_matches_unsharded(recipe_name, overlap):
-    if recipe_name == "mxfp8" and overlap:
-        pytest.skip("the chunked AG+GEMM schedule is per-tensor FP8; MXFP8 gathers in one piece")
     _run("column", recipe_name, overlap)
 
 
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("recipe_name", ["delayed", "current", "mxfp8"])
 def test_row_parallel_sp_matches_unsharded(recipe_name, overlap):
-    if recipe_name == "mxfp8" and overlap:
-        pytest.skip("the chunked GEMM+RS schedule is per-tensor FP8")
     _run("row", recipe_name, overlap)
 
 

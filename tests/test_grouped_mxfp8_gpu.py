@@ -213,6 +213,33 @@ def test_grouped_gemm_mxfp8_accumulate_into_wgrad():
         assert torch.allclose(a, b + f, rtol=1e-6, atol=1e-6)
 
 
+def test_grouped_gemm_mxfp8_member_off_the_128_contract_is_loud():
+    """A member whose first dim is not a multiple of 128 (amd_ext.h contract; m_splits live on the device, so the
+    host cannot check) misplaces the scale offsets of itself AND of every later member: those members' outputs
+    are NaN, the members before it are still exact."""
+    K, N = 256, 256
+    for splits, bad_from in (([256, 160, 224], 1), ([128, 256], None), ([160, 96], 0)):
+        G, x, w, dy, fd = _grouped_case(splits, K, N, 41)
+        M = x.shape[0]
+        q = lambda dt: MXFP8Quantizer(dt, rowwise=True, columnwise=True, columnwise_transposed=True)
+        x8, w8 = group_quantize(x, q(E4), G, first_dims=fd), group_quantize(w, q(E4), G)
+        y = _hp(fd, M, N, G)
+        general_grouped_gemm_for_grouped_tensor(w8, x8, y, layout="TN")
+        torch.cuda.synchronize()
+        yv = y.rowwise_data.view(M, N)
+        r0 = 0
+        for i, m in enumerate(splits):
+            blk = yv[r0:r0 + m]
+            if bad_from is not None and i >= bad_from:
+                assert torch.isnan(blk).all(), f"splits {splits}: member {i} must be NaN"
+            else:
+                qm = MXFP8Quantizer(E4, rowwise=True, columnwise=False)
+                y1, *_ = general_gemm(qm(w[i * N:(i + 1) * N].contiguous()), qm(x[r0:r0 + m].contiguous()),
+                                      out_dtype=torch.float32, layout="TN")
+                assert torch.equal(y1, blk), f"splits {splits}: member {i} differs from the un-grouped GEMM"
+            r0 += m
+
+
 def test_grouped_gemm_mxfp8_needs_transposed_columnwise():
     splits, K, N = [128, 128], 256, 256
     G, x, w, dy, fd = _grouped_case(splits, K, N, 31)

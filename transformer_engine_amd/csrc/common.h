@@ -339,4 +339,19 @@ void scale_from_amax_launch(const float *amax, float *scale, float max_fp8, bool
                             const float *noop, hipStream_t stream);
 void quantize_dispatch(const Tensor &in, const float *noop, Tensor &out, hipStream_t stream);
 
+// Fan a list of independent launches over the compute-stream pool and join them back on the caller's
+// stream (ref common/util/multi_stream.cpp:20-60; callers cublaslt_gemm.cu:994-1045, cast.cu:65-88).
+// Inactive unless NVTE_AMD_MULTI_STREAM is set (quantize_api.cpp): stream_of() is then the caller's stream.
+class MultiStreamScope {
+ public:
+  MultiStreamScope(hipStream_t caller, size_t num_items);
+  hipStream_t stream_of(size_t item) const;
+  void join();  // record every used pool stream's own event, make the caller's stream wait for it
+
+ private:
+  hipStream_t caller_;
+  int mode_ = 0, used_ = 0;
+  bool joined_ = false;
+};
+
 }  // namespace te

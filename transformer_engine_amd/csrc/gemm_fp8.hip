@@ -953,7 +953,7 @@ struct Operand {
 // D = alpha * op(A) op(B) + beta * D  (+bias).  Names follow the reference's cublas_gemm.
 void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, const Tensor *pre_gelu,
                bool transa, bool transb, bool grad, const Tensor *workspace, float alpha, float beta,
-               hipStream_t stream) {
+               hipStream_t stream, int sm_count = 0) {
   const auto [A0, A1] = A.flat2d();
   const auto [B0, B1] = B.flat2d();
   const size_t m = transa ? A0 : A1;
@@ -1114,7 +1114,11 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   g.ntiles = static_cast<unsigned>(ceil_div(n, BM)) * g.tiles_j;
   // Persistent launch: one workgroup per CU walks the tile list; a K of a single tile cannot
   // pipeline across output tiles, so it gets one workgroup per tile.
-  const unsigned cus = static_cast<unsigned>(device_info().num_cus);
+  // `sm_count` > 0 (math_sm_count / kNVTEMatmulConfigSMCount, ref pytorch/csrc/extensions/gemm.cpp:281-298:
+  // the framework leaves NVTE_EXT_MARGIN_SM compute units to the communication kernels of an overlapped
+  // step) caps the persistent grid: the other CUs stay free for whatever runs beside this launch.
+  unsigned cus = static_cast<unsigned>(device_info().num_cus);
+  if (sm_count > 0) cus = std::min(cus, static_cast<unsigned>(sm_count));
   g.grid = (k > BK) ? std::min(g.ntiles, cus) : g.ntiles;
   g.nt_store = (m * n * dtype_bits(D.data.dtype) / 8 > kNtStoreBytes) ? 1u : 0u;
   const bool bias_in_kernel = has_bias && !grad;
@@ -1329,26 +1333,37 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     bytes = static_cast<unsigned>((rows + 127) / 128 * 128) * stride;
   };
   unsigned a_sc_run = 0, b_sc_run = 0;
+  // MXFP8 contract (amd_ext.h): every member's FIRST dim is a multiple of 128.  The quantize kernels write a
+  // member's scales at its global, unpadded row offset while the offsets here are sums of padded sizes; the
+  // two agree only on that contract, so one member off it misplaces the scales of every LATER member too.
+  // `mx_bad_run` = some member up to and including the current one breaks the contract: those members
+  // become NaN like the other inconsistent shapes instead of silently mis-scaled numbers.
+  unsigned mx_bad_run = 0;
   if (mx) {
-    unsigned a_loc = 0, b_loc = 0;
+    unsigned a_loc = 0, b_loc = 0, bad_loc = 0;
     for (unsigned i = lo_i; i < hi_i; ++i) {
       int64_t f, l, o;
       unsigned st, by;
       member_dims(A.shapes, i, f, l, o);
       scale_dims(A, f, l, st, by);
       a_loc += by;
+      bad_loc |= (f % 128 != 0) ? 1u : 0u;
       member_dims(B.shapes, i, f, l, o);
       scale_dims(B, f, l, st, by);
       b_loc += by;
+      bad_loc |= (f % 128 != 0) ? 1u : 0u;
     }
-    unsigned a_incl = a_loc, b_incl = b_loc;
+    unsigned a_incl = a_loc, b_incl = b_loc, bad_incl = bad_loc;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const unsigned ua = __shfl_up(a_incl, off, 64), ub = __shfl_up(b_incl, off, 64);
-      if (lane >= static_cast<unsigned>(off)) { a_incl += ua; b_incl += ub; }
+      const unsigned ubad = __shfl_up(bad_incl, off, 64);
+      if (lane >= static_cast<unsigned>(off)) { a_incl += ua; b_incl += ub; bad_incl |= ubad; }
     }
     a_sc_run = a_incl - a_loc;
     b_sc_run = b_incl - b_loc;
+    const unsigned bad_before = __shfl_up(bad_incl, 1, 64);
+    mx_bad_run = lane > 0 ? bad_before : 0u;
   }
   for (unsigned i = lo_i; i < hi_i; ++i) {
     int64_t a_first, a_last, a_off = 0, b_first, b_last, b_off, d_first, d_last, d_off = 0;
@@ -1385,7 +1400,9 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     const int64_t n = transb ? b_last : b_first, kb = transb ? b_first : b_last;
     // the stores follow D's own shape; anything inconsistent (or a K the 16-byte loads cannot take)
     // turns the member's output into NaN instead of reading out of bounds
-    const bool ok = d_first == n && d_last == m && ka == kb && ka % (mx ? 32 : 16) == 0 && ka <= (1 << 23);
+    if (mx) mx_bad_run |= (a_first % 128 != 0 || b_first % 128 != 0) ? 1u : 0u;
+    const bool ok = d_first == n && d_last == m && ka == kb && ka % (mx ? 32 : 16) == 0 && ka <= (1 << 23) &&
+                    mx_bad_run == 0;
     GroupDesc d;
     d.P = B.base + b_off;
     d.Q = q_ptr;
@@ -1815,10 +1832,10 @@ void nvte_cublas_gemm(const NVTETensor A, const NVTETensor B, NVTETensor D, cons
                       NVTETensor workspace, bool accumulate, bool use_split_accumulator,
                       int math_sm_count, hipStream_t stream) {
   api_guard("nvte_cublas_gemm", [&] {
-    (void)use_split_accumulator; (void)math_sm_count;
+    (void)use_split_accumulator;
     gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
               lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), 1.f, accumulate ? 1.f : 0.f,
-              stream);
+              stream, math_sm_count);
   });
 }
 
@@ -1827,9 +1844,9 @@ void nvte_cublas_gemm_scaled(const NVTETensor A, const NVTETensor B, NVTETensor 
                              bool transb, bool grad, NVTETensor workspace, float alpha, float beta,
                              bool use_split_accumulator, int math_sm_count, hipStream_t stream) {
   api_guard("nvte_cublas_gemm_scaled", [&] {
-    (void)use_split_accumulator; (void)math_sm_count;
+    (void)use_split_accumulator;
     gemm_impl(*lookup_checked(A), *lookup_checked(B), *lookup_checked(D), lookup(bias),
-              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), alpha, beta, stream);
+              lookup(pre_gelu_out), transa, transb, grad, lookup(workspace), alpha, beta, stream, math_sm_count);
   });
 }
 
@@ -1860,7 +1877,7 @@ void nvte_cublas_gemm_v2(int transa, int transb, const float *alpha, const NVTET
       aux = lookup(cfg.epilogue_aux_tensor);
     }
     gemm_impl(a, b, *d, bias_t, aux, transa != 0, transb != 0, grad_epi, lookup(workspace), *alpha, *beta,
-              stream);
+              stream, cfg.sm_count);
   });
 }
 
@@ -1943,21 +1960,23 @@ void nvte_multi_tensor_gemm(const NVTETensor *A, const NVTETensor *B, NVTETensor
                             bool accumulate, bool use_split_accumulator, int math_sm_count,
                             hipStream_t stream) {
   api_guard("nvte_multi_tensor_gemm", [&] {
-    (void)use_split_accumulator; (void)math_sm_count;
+    (void)use_split_accumulator;
     if (num_gemms <= 0) return;
     // The reference fans the list over 4 side streams with event fork / join because one cuBLAS GEMM
     // of an expert-sized problem does not fill an H100 (ref cublaslt_gemm.cu:970-1023).  Here every
     // member is a persistent launch that already spreads over all 256 CUs (a member smaller than the
-    // chip leaves CUs to the next launch: launches of one stream overlap at their tails), so the list
-    // runs in order on the CALLER's stream: no cross-stream events on the hot path, nothing to join,
-    // and capturable in a HIP graph as a plain chain.  (The side-stream version hung intermittently on
-    // this pool's boxes - 4 hardware queues per process shared with the framework's own streams.)
+    // chip leaves CUs to the next launch: launches of one stream overlap at their tails), so by default
+    // the list runs in order on the CALLER's stream: no cross-stream events on the hot path, nothing to
+    // join, and capturable in a HIP graph as a plain chain.  NVTE_AMD_MULTI_STREAM=1 restores the fork /
+    // join over the pool (MultiStreamScope, common.h; DESIGN 3.12 has the history of that switch).
+    MultiStreamScope ms(stream, static_cast<size_t>(num_gemms));
     for (int i = 0; i < num_gemms; ++i) {
       gemm_impl(*lookup_checked(A[i]), *lookup_checked(B[i]), *lookup_checked(D[i]),
                 bias ? lookup(bias[i]) : nullptr, pre_gelu_out ? lookup(pre_gelu_out[i]) : nullptr,
                 transa, transb, grad, workspace ? lookup(workspace[i % nvte_get_num_compute_streams()]) : nullptr,
-                1.f, accumulate ? 1.f : 0.f, stream);
+                1.f, accumulate ? 1.f : 0.f, ms.stream_of(static_cast<size_t>(i)), math_sm_count);
     }
+    ms.join();
   });
 }
 

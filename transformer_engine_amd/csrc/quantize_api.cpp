@@ -4,6 +4,7 @@
 // Replaces: ref common/cast/cast.cu:21-89, common/cast/dispatch/quantize.cuh:33-197,
 //           common/transpose/cast_transpose.cu:348-363, multi_cast_transpose.cu:335,
 //           common/util/multi_stream.cpp:22-67.
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -52,9 +53,16 @@ constexpr int kNumStreams = 4;  // ref multi_stream.cpp:22
 struct StreamPool {
   hipStream_t s[kNumStreams];
   hipEvent_t e[kNumStreams];
+  hipEvent_t fork;  // the fork event of MultiStreamScope: never one of the join events e[]
   bool ready = false;
 };
-// one pool per device ordinal
+int env_int(const char *name, int dflt) {
+  const char *v = std::getenv(name);
+  return (v != nullptr && *v != 0) ? std::atoi(v) : dflt;
+}
+// one pool per device ordinal.  The pool streams have the DEFAULT priority: the reference creates them with
+// priority -1 (multi_stream.cpp:35), which on ROCm puts them on a separate set of high-priority hardware queues
+// whose dispatches pre-empt whatever the framework's own streams run; NVTE_AMD_POOL_PRIORITY=-1 asks for that.
 StreamPool &pool() {
   static std::mutex mu;
   static StreamPool pools[64];
@@ -64,14 +72,45 @@ StreamPool &pool() {
   std::lock_guard<std::mutex> g(mu);
   StreamPool &p = pools[dev];
   if (!p.ready) {
+    const int prio = env_int("NVTE_AMD_POOL_PRIORITY", 0);
     for (int i = 0; i < kNumStreams; ++i) {
-      NVTE_CHECK_HIP(hipStreamCreateWithPriority(&p.s[i], hipStreamNonBlocking, -1));
+      NVTE_CHECK_HIP(hipStreamCreateWithPriority(&p.s[i], hipStreamNonBlocking, prio));
       NVTE_CHECK_HIP(hipEventCreateWithFlags(&p.e[i], hipEventDisableTiming));
     }
+    NVTE_CHECK_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
     p.ready = true;
   }
   return p;
 }
+
+}  // namespace
+
+// NVTE_AMD_MULTI_STREAM: 0 (default) = list entry points run in order on the caller's stream;
+// 1 = fork / join over the pool with a dedicated fork event; 2 = the shape of the reference
+// (cublaslt_gemm.cu:994-1045, cast.cu:65-88): join event 0 doubles as the fork event.
+MultiStreamScope::MultiStreamScope(hipStream_t caller, size_t num_items) : caller_(caller) {
+  mode_ = env_int("NVTE_AMD_MULTI_STREAM", 0);
+  if (mode_ == 0 || num_items == 0) { mode_ = 0; return; }
+  StreamPool &p = pool();
+  used_ = static_cast<int>(std::min<size_t>(num_items, kNumStreams));
+  hipEvent_t fork = mode_ == 2 ? p.e[0] : p.fork;
+  NVTE_CHECK_HIP(hipEventRecord(fork, caller_));
+  for (int s = 0; s < used_; ++s) NVTE_CHECK_HIP(hipStreamWaitEvent(p.s[s], fork, 0));
+}
+hipStream_t MultiStreamScope::stream_of(size_t item) const {
+  return mode_ == 0 ? caller_ : pool().s[item % kNumStreams];
+}
+void MultiStreamScope::join() {
+  if (mode_ == 0 || joined_) return;
+  joined_ = true;
+  StreamPool &p = pool();
+  for (int s = 0; s < used_; ++s) {
+    NVTE_CHECK_HIP(hipEventRecord(p.e[s], p.s[s]));
+    NVTE_CHECK_HIP(hipStreamWaitEvent(caller_, p.e[s], 0));
+  }
+}
+
+namespace {
 
 void with_config(const NVTETensor input, NVTETensor output, const QuantConfig *cfg,
                  hipStream_t stream) {
@@ -138,11 +177,13 @@ void nvte_multi_tensor_quantize(const NVTETensor *inputs, NVTETensor *outputs,
                                 const NVTEQuantizationConfig quant_config, const size_t num_tensors,
                                 hipStream_t stream) {
   api_guard("nvte_multi_tensor_quantize", [&] {
-    // In order on the caller's stream (the reference forks over 4 side streams, ref cast.cu:65-88):
-    // every quantize kernel here is a full-chip HBM-bound launch, so side streams add event traffic
-    // and nothing else; see nvte_multi_tensor_gemm.
+    // In order on the caller's stream by default (the reference forks over 4 side streams, ref cast.cu:65-88):
+    // every quantize kernel here is a full-chip HBM-bound launch, so side streams add event traffic and
+    // nothing else; NVTE_AMD_MULTI_STREAM=1 restores the fork / join (common.h MultiStreamScope).
+    MultiStreamScope ms(stream, num_tensors);
     for (size_t i = 0; i < num_tensors; ++i)
-      with_config(inputs[i], outputs[i], static_cast<const QuantConfig *>(quant_config), stream);
+      with_config(inputs[i], outputs[i], static_cast<const QuantConfig *>(quant_config), ms.stream_of(i));
+    ms.join();
   });
 }
 

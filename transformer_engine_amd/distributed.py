@@ -36,6 +36,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+from . import _dist_flags as _flags
 from .recipe import DelayedScaling, Float8CurrentScaling, MXFP8BlockScaling, reduce_and_update_fp8_tensors
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, Float8Tensor,
                      MXFP8Quantizer, MXFP8Tensor)
@@ -51,6 +52,19 @@ def _is_gloo(group) -> bool:
     return dist.is_initialized() and dist.get_backend(group) == "gloo"
 
 
+def force_collectives(flag: bool = True) -> None:
+    """Issue every collective even in a group of ONE rank (default: a single rank returns its input).  With a
+    world-size-1 ``nccl`` group this runs the RCCL branch of every helper below - all_gather_into_tensor,
+    reduce_scatter_tensor, all_reduce(MAX), ``work.wait()`` stream ordering beside the persistent GEMMs - on a
+    one-GPU box (tests/test_rccl_single_gpu.py).  Also set by NVTE_AMD_FORCE_COLLECTIVES=1."""
+    _flags.FORCE_COLLECTIVES = bool(flag)
+
+
+def collectives_active(group=None) -> bool:
+    """True when the helpers of this module communicate: more than one rank, or forced (see above)."""
+    return _flags.collectives_active(group)
+
+
 # ---------------------------------------------------------------------------------------
 # plain-tensor collectives
 # ---------------------------------------------------------------------------------------
@@ -64,7 +78,7 @@ class _Done:
 def all_gather_rows(local: torch.Tensor, group=None, async_op: bool = False):
     """[m, ...] per rank -> [tp*m, ...] (rank-major).  One all_gather_into_tensor."""
     tp = get_distributed_world_size(group)
-    if tp == 1:
+    if not collectives_active(group):
         return local, None
     if _is_gloo(group) and local.is_cuda:
         # rehearsal path (two ranks on one GPU): staged through the host and finished on return; gloo's
@@ -84,7 +98,7 @@ def all_gather_rows(local: torch.Tensor, group=None, async_op: bool = False):
 def reduce_scatter_along_first_dim(x: torch.Tensor, group=None, async_op: bool = False):
     """[tp*m, ...] partial sums -> [m, ...] (ref pytorch/distributed.py:928-955)."""
     tp = get_distributed_world_size(group)
-    if tp == 1:
+    if not collectives_active(group):
         return x, None
     assert x.shape[0] % tp == 0, "first dim must divide by the tensor-parallel size"
     if _is_gloo(group):
@@ -104,7 +118,7 @@ def reduce_scatter_along_first_dim(x: torch.Tensor, group=None, async_op: bool =
 
 def allreduce(x: torch.Tensor, group=None, async_op: bool = False):
     """ref pytorch/distributed.py:2051-2065"""
-    if get_distributed_world_size(group) == 1:
+    if not collectives_active(group):
         return x, None
     handle = dist.all_reduce(x, group=group, async_op=async_op)
     return x, handle
@@ -112,7 +126,7 @@ def allreduce(x: torch.Tensor, group=None, async_op: bool = False):
 
 def all_reduce_max_(t: torch.Tensor, group=None) -> None:
     """In-place MAX all-reduce of an amax buffer (gloo rehearsals reduce on the host)."""
-    if get_distributed_world_size(group) == 1:
+    if not collectives_active(group):
         return
     if _is_gloo(group) and t.is_cuda:
         h = t.cpu()
@@ -145,13 +159,15 @@ def gather_and_gemm_kchunked(local: torch.Tensor, gemm: Callable[[torch.Tensor, 
     ``[tp*m, k1-k0]`` buffer (natural row order) is handed to ``gemm(buf, i, k0, k1)`` as soon as ITS
     all-gather has landed; all collectives are issued up front (they run back to back on the
     communication stream, each using every link).  Returns the gathered chunks."""
-    tp = get_distributed_world_size(group)
+    active = collectives_active(group)
     m, K = local.shape
-    pts = split_points(K, chunks if tp > 1 else 1, align)
+    pts = split_points(K, chunks if active else 1, align)
     bufs, works = [], []
     for k0, k1 in pts:
+        # the collective's input must be contiguous: one strided copy of the LOCAL shard's chunk (1/tp of the
+        # gathered bytes; the gathered chunks themselves land contiguous and are never copied)
         piece = local if (k0 == 0 and k1 == K) else local[:, k0:k1].contiguous()
-        if tp == 1:
+        if not active:
             bufs.append(piece); works.append(None)
             continue
         out, work = all_gather_rows(piece, group, async_op=True)
@@ -169,8 +185,7 @@ def gemm_and_reduce_scatter_nchunked(n_cols: int, gemm: Callable[[int, int], tor
     """GEMM + RS overlap, cut along the output columns.  ``gemm(c0, c1)`` returns the partial sums
     ``[M, c1-c0]`` (contiguous); its reduce-scatter runs while the next piece is computed.  Returns
     this rank's ``[M/tp, n_cols]``."""
-    tp = get_distributed_world_size(group)
-    pts = split_points(n_cols, chunks if tp > 1 else 1, align)
+    pts = split_points(n_cols, chunks if collectives_active(group) else 1, align)
     outs, works = [], []
     for c0, c1 in pts:
         part = gemm(c0, c1)
@@ -279,6 +294,40 @@ def _all_gather_mxfp8(q: MXFP8Tensor, group=None) -> MXFP8Tensor:
                        quantizer=q._quantizer, columnwise_transposed=cd is not None)
 
 
+def _mx_k_slice(w8: MXFP8Tensor, k0: int, k1: int) -> MXFP8Tensor:
+    """Rowwise MXFP8 operand restricted to the contraction range [k0, k1) (multiples of 128): a copy of the
+    payload columns and of the matching scales (compact: columns k/32; GEMM-swizzled: whole 128-row x 4-block
+    tiles, 512 bytes each, tile (row tile, k tile) at index row_tile * K/128 + k_tile)."""
+    K = w8.shape[-1]
+    rows = w8.numel() // K
+    assert k0 % 128 == 0 and (k1 % 128 == 0 or k1 == K) and K % 128 == 0
+    data = w8._rowwise_data.view(rows, K)[:, k0:k1].contiguous()
+    sc = w8._rowwise_scale_inv
+    if w8._with_gemm_swizzled_scales:
+        rt = sc.numel() // ((K // 128) * 512)
+        sc = sc.view(rt, K // 128, 512)[:, k0 // 128:k1 // 128].contiguous().view(rt * 128, (k1 - k0) // 32)
+    else:
+        sc = sc[:, k0 // 32:k1 // 32].contiguous()
+    return MXFP8Tensor(shape=(rows, k1 - k0), dtype=w8.dtype, rowwise_data=data, rowwise_scale_inv=sc,
+                       columnwise_data=None, columnwise_scale_inv=None, fp8_dtype=w8._fp8_dtype,
+                       with_gemm_swizzled_scales=w8._with_gemm_swizzled_scales)
+
+
+def _mx_row_slice(w8: MXFP8Tensor, r0: int, r1: int) -> MXFP8Tensor:
+    """Rows [r0, r1) (multiples of 128) of a rowwise MXFP8 operand: views, no copy (a compact scale matrix is
+    row-major, a swizzled one is stored by 128-row tiles)."""
+    K = w8.shape[-1]
+    rows = w8.numel() // K
+    assert r0 % 128 == 0 and (r1 % 128 == 0 or r1 == rows)
+    data = w8._rowwise_data.view(rows, K)[r0:r1]
+    sc = w8._rowwise_scale_inv
+    stride = sc.numel() // ((rows + 127) // 128 * 128)
+    sc2 = sc.view(-1, stride)[r0:(r1 + 127) // 128 * 128]
+    return MXFP8Tensor(shape=(r1 - r0, K), dtype=w8.dtype, rowwise_data=data, rowwise_scale_inv=sc2,
+                       columnwise_data=None, columnwise_scale_inv=None, fp8_dtype=w8._fp8_dtype,
+                       with_gemm_swizzled_scales=w8._with_gemm_swizzled_scales)
+
+
 def gather_along_first_dim(inp, group=None, quantizer=None, need_transpose: bool = False):
     """ref pytorch/distributed.py:1665: quantize locally (rowwise only for per-tensor FP8: a gathered
     transpose is not the transpose of the gather, linear.py:361-363), then all-gather bytes."""
@@ -301,7 +350,7 @@ def configure_amax_reduction(quantizer, group) -> None:
     every rank.  Current scaling: the amax is MAX-all-reduced over the group before the scale is
     computed (ref module/linear.py:319-322, csrc/quantizer.cpp:994-999).  Delayed scaling gets the same
     from the recipe step's packed amax all-reduce; MXFP8 scales are per block and need nothing."""
-    if isinstance(quantizer, Float8CurrentScalingQuantizer) and get_distributed_world_size(group) > 1:
+    if isinstance(quantizer, Float8CurrentScalingQuantizer) and collectives_active(group):
         quantizer.with_amax_reduction = True
         quantizer.amax_reduction_group = group
 
@@ -343,11 +392,16 @@ class ColumnParallelLinearSP:
             self._w_chunks = None
         return st.weight_cache
 
-    def _weight_k_chunks(self, w8: Float8Tensor, pts):
+    def _weight_k_chunks(self, w8, pts):
+        """K slices of the cached FP8 weight, rebuilt only when the weight is re-quantized.  MXFP8: the payload
+        columns [k0, k1) and the matching scale columns (compact) or whole 128 x 4 scale tiles (swizzled)."""
         if self._w_chunks is None or self._w_chunks[0] != pts:
-            views = [Float8Tensor(shape=(self.N_local, k1 - k0), dtype=w8.dtype,
-                                  data=w8._data[:, k0:k1].contiguous(), fp8_scale_inv=w8._scale_inv,
-                                  fp8_dtype=w8._fp8_dtype) for k0, k1 in pts]
+            if isinstance(w8, MXFP8Tensor):
+                views = [_mx_k_slice(w8, k0, k1) for k0, k1 in pts]
+            else:
+                views = [Float8Tensor(shape=(self.N_local, k1 - k0), dtype=w8.dtype,
+                                      data=w8._data[:, k0:k1].contiguous(), fp8_scale_inv=w8._scale_inv,
+                                      fp8_dtype=w8._fp8_dtype) for k0, k1 in pts]
             self._w_chunks = (pts, views)
         return self._w_chunks[1]
 
@@ -364,23 +418,63 @@ class ColumnParallelLinearSP:
         """Returns (y, x8 for backward)."""
         from .gemm import general_gemm
         tp = self.tp
-        y = torch.empty(m * tp, self.N_local, dtype=self.out_dtype, device=self.device)
-        if self.overlap and tp > 1 and isinstance(x8_local, Float8Tensor):
-            pts = tuple(split_points(self.K, self.chunks))
+        pts = tuple(split_points(self.K, self.chunks)) if (self.overlap and collectives_active(self.group)) else ()
+        if len(pts) > 1:
+            # The chunk GEMMs accumulate in FP32 and the sum is rounded to the output dtype ONCE (a bf16
+            # accumulator would round after every chunk, ADVICE r2): the result then differs from the unsplit
+            # GEMM only by the fp32 rounding of the per-chunk partial sums.
+            y_acc = torch.empty(m * tp, self.N_local, dtype=torch.float32, device=self.device)
             w_chunks = self._weight_k_chunks(w8, pts)
+            if isinstance(x8_local, Float8Tensor):
+                def chunk_gemm(buf, i, k0, k1):
+                    xs = Float8Tensor(shape=(m * tp, k1 - k0), dtype=self.out_dtype, data=buf,
+                                      fp8_scale_inv=x8_local._scale_inv, fp8_dtype=x8_local._fp8_dtype)
+                    general_gemm(w_chunks[i], xs, layout="TN", out=y_acc, accumulate=i > 0)
 
-            def chunk_gemm(buf, i, k0, k1):
-                xs = Float8Tensor(shape=(m * tp, k1 - k0), dtype=self.out_dtype, data=buf,
-                                  fp8_scale_inv=x8_local._scale_inv, fp8_dtype=x8_local._fp8_dtype)
-                general_gemm(w_chunks[i], xs, layout="TN", out=y, accumulate=i > 0)
-
-            bufs = gather_and_gemm_kchunked(x8_local._data.view(m, self.K), chunk_gemm, self.group, self.chunks)
-            # backward only needs X^T: the transposes of the gathered chunks are its row blocks
-            x8 = _GatheredChunks(bufs, pts, x8_local)
+                bufs = gather_and_gemm_kchunked(x8_local._data.view(m, self.K), chunk_gemm, self.group, self.chunks)
+                # backward only needs X^T: the transposes of the gathered chunks are its row blocks
+                x8 = _GatheredChunks(bufs, pts, x8_local)
+            else:
+                x8 = self._gather_and_gemm_mx(x8_local, w_chunks, pts, m, y_acc)
+            y = y_acc.to(self.out_dtype)
         else:
+            y = torch.empty(m * tp, self.N_local, dtype=self.out_dtype, device=self.device)
             x8 = gather_along_first_dim(x8_local, self.group)
             general_gemm(w8, x8, layout="TN", out=y)
         return y, x8
+
+    def _gather_and_gemm_mx(self, x8_local: MXFP8Tensor, w_chunks, pts, m, y_acc):
+        """The K-chunked schedule for MXFP8 (the reference's split_overlap_ag is recipe-agnostic,
+        comm_gemm_overlap.cpp:1044-1216): chunk i = payload columns [k0, k1) and their e8m0 scale columns, two
+        collectives per chunk that both land contiguous (nothing gathered is copied); the transposed
+        columnwise pair that only backward reads is gathered behind the chunk GEMMs."""
+        from .gemm import general_gemm
+        tp = self.tp
+        assert not x8_local._with_gemm_swizzled_scales, "the gathered operand keeps compact scales"
+        data = x8_local._rowwise_data.view(m, self.K)
+        sc = x8_local._rowwise_scale_inv
+        gathered, works = [], []
+        for k0, k1 in pts:
+            d_out, d_work = all_gather_rows(data[:, k0:k1].contiguous(), self.group, async_op=True)
+            s_out, s_work = all_gather_rows(sc[:m, k0 // 32:k1 // 32].contiguous(), self.group, async_op=True)
+            gathered.append((d_out, s_out)); works.append((d_work, s_work))
+        rows_pad = (-(m * tp)) % 128
+        for i, (k0, k1) in enumerate(pts):
+            for w in works[i]:
+                if w is not None:
+                    w.wait()
+            xs_data, xs_sc = gathered[i]
+            if rows_pad:
+                xs_sc = torch.cat([xs_sc, torch.zeros(rows_pad, xs_sc.shape[1], dtype=xs_sc.dtype, device=xs_sc.device)])
+            xs = MXFP8Tensor(shape=(m * tp, k1 - k0), dtype=self.out_dtype, rowwise_data=xs_data,
+                             rowwise_scale_inv=xs_sc, columnwise_data=None, columnwise_scale_inv=None,
+                             fp8_dtype=x8_local._fp8_dtype)
+            general_gemm(w_chunks[i], xs, layout="TN", out=y_acc, accumulate=i > 0)
+        col_only = MXFP8Tensor(shape=x8_local.shape, dtype=x8_local.dtype, rowwise_data=None, rowwise_scale_inv=None,
+                               columnwise_data=x8_local._columnwise_data,
+                               columnwise_scale_inv=x8_local._columnwise_scale_inv, fp8_dtype=x8_local._fp8_dtype,
+                               quantizer=x8_local._quantizer, columnwise_transposed=x8_local._columnwise_transposed)
+        return _all_gather_mxfp8(col_only, self.group)
 
     def forward(self, x_local: torch.Tensor, is_first_microbatch=None):
         st = self.state
@@ -504,7 +598,7 @@ class ColumnParallelLayerNormLinearSP(ColumnParallelLinearSP):
             dx, dgamma = rmsnorm_bwd(dln_local, x2d, rsigma, self.layer_norm_weight,
                                      zero_centered_gamma=self.zero_centered_gamma)
             dbeta = None
-        if self.allreduce_norm_grads and self.tp > 1:
+        if self.allreduce_norm_grads and collectives_active(self.group):
             for t in (dgamma, dbeta):
                 if t is not None:
                     _all_reduce_sum_(t, self.group)
@@ -563,10 +657,13 @@ class RowParallelLinearSP:
         qi.set_usage(rowwise=True, columnwise=True)
         x8 = qi(x)
         M = x.shape[0]
-        if self.overlap and self.tp > 1 and isinstance(w8, Float8Tensor):
+        if self.overlap and collectives_active(self.group):
             def cols_gemm(c0, c1):
-                wj = Float8Tensor(shape=(c1 - c0, self.K_local), dtype=w8.dtype, data=w8._data[c0:c1],
-                                  fp8_scale_inv=w8._scale_inv, fp8_dtype=w8._fp8_dtype)
+                if isinstance(w8, MXFP8Tensor):
+                    wj = _mx_row_slice(w8, c0, c1)
+                else:
+                    wj = Float8Tensor(shape=(c1 - c0, self.K_local), dtype=w8.dtype, data=w8._data[c0:c1],
+                                      fp8_scale_inv=w8._scale_inv, fp8_dtype=w8._fp8_dtype)
                 out, *_ = general_gemm(wj, x8, out_dtype=self.out_dtype, layout="TN")
                 return out
             y_local = gemm_and_reduce_scatter_nchunked(self.N, cols_gemm, self.group, self.chunks)

@@ -11,6 +11,7 @@ Layout semantics for a Linear with tokens M, in K, out N
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -43,6 +44,17 @@ def gemm_output_shape(a_shape, b_shape, transa: bool, transb: bool) -> Tuple[int
     if transb:
         return (b_shape[-1], m)
     return tuple(b_shape[:-1]) + (m,)
+
+
+_CUS = {}
+
+
+def _num_cus(dev) -> int:
+    idx = torch.device(dev).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _CUS:
+        _CUS[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return _CUS[idx]
 
 
 def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_params=None,
@@ -157,6 +169,13 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
                                                  C.byref(one), 1)
         b8 = C.c_uint8(1 if use_split_accumulator else 0)
         api.nvte_set_matmul_config_attribute(cfg, _lib.kMUseSplitAccumulator, C.byref(b8), 1)
+        # external margin for every GEMM (ref csrc/extensions/gemm.cpp:281-298): NVTE_EXT_MARGIN_SM compute units
+        # stay free for the communication kernels of an overlapped step; 0 = the whole chip
+        margin = os.environ.get("NVTE_EXT_MARGIN_SM")
+        if margin:
+            cus = _num_cus(dev)
+            smc = C.c_int(max(cus - int(margin), 0))
+            api.nvte_set_matmul_config_attribute(cfg, _lib.kMSMCount, C.byref(smc), C.sizeof(smc))
         al, be = C.c_float(alpha), C.c_float(beta)
         wws = wrap_plain(get_workspace(dev))
         api.nvte_cublas_gemm_v2(int(transa), int(transb), C.byref(al), wa.handle, wb.handle,

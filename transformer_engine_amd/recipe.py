@@ -14,6 +14,7 @@ from typing import List, Optional
 
 import torch
 
+from . import _dist_flags as _flags
 from . import _lib
 from ._lib import api
 from .tensor import (DType, Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantizer,
@@ -123,8 +124,7 @@ def reduce_and_update_fp8_tensors(states: List[DelayedScalingRecipeState], group
     recipe = states[0].recipe
     import torch.distributed as dist
     # group=None means the default (world) group, as in torch.distributed
-    reduce = (recipe.reduce_amax and dist.is_available() and dist.is_initialized()
-              and dist.get_world_size(group) > 1)
+    reduce = recipe.reduce_amax and _flags.collectives_active(group)
     # single process: no packed buffer (and no copy kernel) at all
     contiguous_amax = torch.cat([s.amax_history[0] for s in states]) if reduce else None
     if reduce:
