@@ -41,7 +41,7 @@ s.record(); fn(); e.record(); torch.cuda.synchronize()
 stamped = s.elapsed_time(e)
 lib.nvte_amd_debug_set_gemm_wait_stamps(None)
 d = ws.cpu().numpy().reshape(256, 8, 8).astype(np.float64)
-vm, bar, loop, tiles, epi, yseg = d[..., 0], d[..., 1], d[..., 2], d[..., 3], d[..., 4], d[..., 5]
+vm, bar, loop, tiles, epi, yseg, bar2 = d[..., 0], d[..., 1], d[..., 2], d[..., 3], d[..., 4], d[..., 5], d[..., 6]
 np.set_printoptions(linewidth=200, precision=1, suppress=True)
 print(f"{role} dbg={os.environ.get('TE_GEMM_DBG', '0')}: launch {plain * 1e3:.1f} us without stamps, {stamped * 1e3:.1f} us with; K tiles per wave {tiles.mean():.0f}")
 print("cycles per K tile, mean over workgroups, by wave 0..7:")
@@ -50,6 +50,7 @@ print("  parked in vmcnt(0) wait   ", (vm / tiles).mean(axis=0))
 print("  parked in s_barrier       ", (bar / tiles).mean(axis=0))
 print("  epilogue cycles per K tile", (epi / tiles).mean(axis=0))
 print("  post-barrier segment (6 MFMAs + 8 LDS-DMA + 12 ds_read)", (yseg / tiles).mean(axis=0))
-print("  pre-barrier segment (10 MFMAs + 12 ds_read)            ", ((loop - vm - bar - epi - yseg) / tiles).mean(axis=0))
+print("  parked in the Y-segment barrier", (bar2 / tiles).mean(axis=0))
+print("  X segment (10 MFMAs + 12 ds_read)                      ", ((loop - vm - bar - epi - yseg - bar2) / tiles).mean(axis=0))
 print(f"shares of the K-loop span: vmcnt wait {vm.sum() / loop.sum():.3f}, barrier {bar.sum() / loop.sum():.3f}; epilogue / (loop span) {epi.sum() / loop.sum():.3f}")
 print("ideal MFMA cycles per K tile: 2048")
