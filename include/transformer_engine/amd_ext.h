@@ -36,6 +36,17 @@ void nvte_amd_delayed_scaling_after_reduction(const NVTETensor amax_reduction_bu
                                               enum NVTEDType fp8_dtype, float margin,
                                               hipStream_t stream);
 
+/* The same bulk update with ONE FP8 format per tensor, so that the forward (E4M3) and backward (E5M2 under
+ * the HYBRID format) recipe states of a step share one launch: the reference issues one call per direction
+ * (ref pytorch/quantization.py:646-701, recipe.h:71-74); a layer's two states are independent, so updating
+ * both behind the backward pass gives the values of the two separate calls. */
+void nvte_amd_delayed_scaling_after_reduction_multi(const NVTETensor amax_reduction_buffer,
+                                                    const NVTETensor *amax_histories,
+                                                    const NVTETensor *scales,
+                                                    const enum NVTEDType *fp8_dtypes,
+                                                    size_t num_tensors, const char *amax_compute_algo,
+                                                    float margin, hipStream_t stream);
+
 /* MXFP8 "transposed columnwise" layout (no counterpart in the reference).
  * The reference keeps the columnwise-quantized MXFP8 payload in the input's own [rows, cols]
  * layout and lets cuBLASLt read it as a non-TN operand.  gfx950's MFMA needs K-contiguous

@@ -1,6 +1,6 @@
 """Same-box A/B of two builds of the library on the configs[1] GEMMs (+ MXFP8 8192^3): one child process per
 build and round, interleaved, >= 1 s of warm-up under load, median of the rounds.
-usage: python scratch/perf_gemm_ab.py <libA.so> <libB.so> [rounds]"""
+usage: python scratch/perf_gemm_ab.py <libA.so> <libB.so> [<libC.so> ...] [rounds]"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -38,8 +38,8 @@ for name, f in fns.items():
     res[name] = s.elapsed_time(e) / 30 * 1e3
 print("RES", json.dumps(res))
 ''' % ROOT
-libs = sys.argv[1:3]
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+libs = [a for a in sys.argv[1:] if not a.isdigit()]
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 acc = {l: {} for l in libs}
 for r in range(rounds):
     for l in libs:

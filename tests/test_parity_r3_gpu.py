@@ -215,3 +215,102 @@ def test_dense_gemm_capped_workgroup_count_exact(cus, mx, monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(y_all.double(), ref)
     assert torch.equal(y_cap.double(), ref)
+
+
+# ------------------------------------------------------------------------------------------ recipe step, one launch
+def test_recipe_update_fwd_bwd_in_one_launch_equals_two_calls():
+    """LinearFP8State.update_fwd_bwd (nvte_amd_delayed_scaling_after_reduction_multi: one FP8 format per tensor, so the
+    E4M3 forward state and the E5M2 backward state share a launch) against the reference's two calls per step
+    (ref pytorch/quantization.py:646-701): histories, scales and every output bit-equal over 4 steps."""
+    from transformer_engine_amd import linear as L
+    from transformer_engine_amd.recipe import DelayedScaling
+    M, K, N = 512, 384, 640
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    sa = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"))
+    sb = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"))
+    for it in range(4):
+        x = (torch.randn(M, K, generator=g) * (1.0 + it)).to(torch.bfloat16).cuda()
+        dy = (torch.randn(M, N, generator=g) * 0.01 * (4 - it)).to(torch.bfloat16).cuda()
+        ya, saved = L.linear_forward(x, w, None, sa, is_first_microbatch=True)
+        sa.update_fwd()
+        dxa, dwa, _ = L.linear_backward(dy, saved, sa)
+        sa.update_bwd()
+        yb, saved = L.linear_forward(x, w, None, sb, is_first_microbatch=True)
+        dxb, dwb, _ = L.linear_backward(dy, saved, sb)
+        sb.update_fwd_bwd()
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb) and torch.equal(dxa, dxb) and torch.equal(dwa, dwb), it
+        for a, b in ((sa.fwd_state, sb.fwd_state), (sa.bwd_state, sb.bwd_state)):
+            assert torch.equal(a.scale, b.scale) and torch.equal(a.amax_history, b.amax_history), it
+    assert sa.fwd_state.scale[0].item() != 1.0 and sa.bwd_state.scale[0].item() != 1.0
+
+
+# ------------------------------------------------------------------------------------------ GroupedLinear, delayed scaling + list path
+@pytest.mark.parametrize("recipe_name", ["delayed", "current", "mxfp8"])
+def test_grouped_linear_recipes_grouped_path_list_path_and_per_expert_linear(recipe_name):
+    """GroupedLinear under DelayedScaling (one scale / amax history per expert and operand, ref
+    module/grouped_linear.py quantizer layout), current scaling and MXFP8, three ways over 3 steps:
+    the grouped path (device-side splits), the legacy list path (host m_splits, split_quantize + nvte_multi_tensor_gemm,
+    ref module/grouped_linear.py:630-697) and one te.Linear-style state per expert.  Same quantization, same kernel
+    arithmetic: outputs, scales and amax histories bit-equal."""
+    from transformer_engine_amd.grouped_linear import (GroupedLinearFP8State, grouped_linear_backward,
+                                                       grouped_linear_backward_list, grouped_linear_forward,
+                                                       grouped_linear_forward_list)
+    from transformer_engine_amd.linear import LinearFP8State, linear_backward, linear_forward
+    from transformer_engine_amd.recipe import DelayedScaling, Float8CurrentScaling, MXFP8BlockScaling
+    mk = {"delayed": lambda: DelayedScaling(amax_history_len=4), "current": Float8CurrentScaling,
+          "mxfp8": MXFP8BlockScaling}[recipe_name]
+    G, K, N = 3, 256, 384
+    m_splits = [256, 128, 384] if recipe_name == "mxfp8" else [128, 0, 400]     # MXFP8 members: multiples of 128 rows
+    M = sum(m_splits)
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(G * N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    ws = [w[i * N:(i + 1) * N].contiguous() for i in range(G)]
+    fd = torch.tensor(m_splits, dtype=torch.int64, device="cuda")
+    st_g, st_l = GroupedLinearFP8State(mk(), G), GroupedLinearFP8State(mk(), G)
+    st_e = [LinearFP8State(mk()) for _ in range(G)]
+    for it in range(3):
+        x = (torch.randn(M, K, generator=g) * (1.0 + it)).to(torch.bfloat16).cuda()
+        dy = (torch.randn(M, N, generator=g) * 0.01).to(torch.bfloat16).cuda()
+        # per-expert magnitudes differ, so a scale applied to the wrong expert shows
+        r0 = 0
+        for i, m in enumerate(m_splits):
+            x[r0:r0 + m] *= 2.0 ** i
+            r0 += m
+        yg, saved = grouped_linear_forward(x, w, fd, st_g, is_first_microbatch=True)
+        st_g.update_fwd()
+        dxg, dwg = grouped_linear_backward(dy, saved, fd, st_g)
+        st_g.update_bwd()
+        yl, saved = grouped_linear_forward_list(x, ws, m_splits, st_l, is_first_microbatch=True)
+        st_l.update_fwd()
+        dxl, dwl = grouped_linear_backward_list(dy, saved, st_l)
+        st_l.update_bwd()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, yl) and torch.equal(dxg, dxl), f"step {it}: grouped vs list path"
+        r0 = 0
+        for i, m in enumerate(m_splits):
+            if m == 0:
+                assert torch.equal(dwg[i], torch.zeros_like(dwg[i])) and torch.equal(dwl[i], dwg[i])
+                continue
+            assert torch.equal(dwg[i], dwl[i]), f"step {it}: wgrad {i} grouped vs list"
+            yi, sv = linear_forward(x[r0:r0 + m].contiguous(), ws[i], None, st_e[i], is_first_microbatch=True)
+            st_e[i].update_fwd()
+            dxi, dwi, _ = linear_backward(dy[r0:r0 + m].contiguous(), sv, st_e[i])
+            st_e[i].update_bwd()
+            torch.cuda.synchronize()
+            assert torch.equal(yg[r0:r0 + m], yi), f"step {it}: fprop member {i}"
+            assert torch.equal(dxg[r0:r0 + m], dxi), f"step {it}: dgrad member {i}"
+            assert torch.equal(dwg[i], dwi), f"step {it}: wgrad member {i}"
+            if recipe_name == "delayed":
+                # expert i's input / weight / grad scales equal the single Linear's (FWD_INPUT = 0, FWD_WEIGHT = 1)
+                fs, es = st_g.fwd_state, st_e[i].fwd_state
+                assert fs.scale[i].item() == es.scale[0].item() and fs.scale[G + i].item() == es.scale[1].item()
+                assert torch.equal(fs.amax_history[:, i], es.amax_history[:, 0])
+                assert st_g.bwd_state.scale[i].item() == st_e[i].bwd_state.scale[0].item()
+            r0 += m
+        if recipe_name == "delayed":
+            assert torch.equal(st_g.fwd_state.scale, st_l.fwd_state.scale)
+            assert torch.equal(st_g.bwd_state.amax_history, st_l.bwd_state.amax_history)
+    if recipe_name == "delayed":
+        assert (st_g.fwd_state.scale[[0, 2]] != 1.0).all(), "delayed scales never moved"

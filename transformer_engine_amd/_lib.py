@@ -115,6 +115,7 @@ _SIGS = {
     "nvte_amd_get_grouped_columnwise_transposed": (_I, [_P]),
     "nvte_amd_get_columnwise_transposed": (_I, [_P]),
     "nvte_amd_delayed_scaling_after_reduction": (_V, [_P, C.POINTER(_P), C.POINTER(_P), _SZ, C.c_char_p, _I, _F, _P]),
+    "nvte_amd_delayed_scaling_after_reduction_multi": (_V, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I), _SZ, C.c_char_p, _F, _P]),
     # transformer_engine.h
     "nvte_create_tensor": (_P, [_I]),
     "nvte_create_tensors": (_V, [_I, C.POINTER(_P), _SZ]),

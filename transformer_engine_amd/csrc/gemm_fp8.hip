@@ -51,6 +51,12 @@ constexpr int kStageBytes = (BM + BN) * BK;  // 64 KiB
 constexpr int kScaleSlotBytes = 2048;        // MX: e8m0 scale dwords of one K tile, 256 P rows + 256 Q rows
 constexpr unsigned kOOB = 0x80000000u;
 constexpr size_t kNtStoreBytes = 32u << 20;  // outputs beyond this are written with streaming stores
+// cache-policy bits of the operand staging loads (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1); a build-time
+// knob for A/B runs (make variant), the shipped value is the measured best
+#ifndef TE_GEMM_AUX
+#define TE_GEMM_AUX 0
+#endif
+constexpr int kStageAux = TE_GEMM_AUX;
 
 struct GemmArgs {
   const uint8_t *P;   // [n, k]
@@ -391,8 +397,8 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(t.qbase, 0, t.qbytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, kStageAux);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, kStageAux);
   };
   auto stage_voff = [&](const TileCtx &t, unsigned k0, unsigned(&voff)[2]) {
 #pragma unroll

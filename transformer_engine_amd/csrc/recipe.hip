@@ -197,13 +197,14 @@ struct BulkEntry {
   float *scale;
   int num_scale;
   int buf_offset;  // first entry of this tensor in the reduced-amax buffer
+  float scaled_max;  // fp8_max of THIS tensor's format * 2^-margin (forward and backward states differ)
 };
 struct BulkParams {
   BulkEntry e[kBulk];
 };
 
 __global__ __launch_bounds__(kDsThreads) void delayed_scaling_bulk_kernel(
-    const float *reduced, BulkParams p, size_t length, AmaxAlgo algo, float scaled_max) {
+    const float *reduced, BulkParams p, size_t length, AmaxAlgo algo) {
   __shared__ float red[kDsThreads / 64];
   const BulkEntry ent = p.e[blockIdx.x];
   const int col = blockIdx.y;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kDsThreads) void delayed_scaling_bulk_kernel(
   // a column with no recorded amax (last == 0) is left alone, its reduction is 0 (-> the old scale stays)
   const float amax = roll_column<kDsThreads>(hist, hist, length, ent.num_scale,
                                              [&] { return r != 0.0f ? r : head; }, true, algo, red, last);
-  if (threadIdx.x == 0) ent.scale[col] = updated_scale(amax, old_scale, scaled_max);
+  if (threadIdx.x == 0) ent.scale[col] = updated_scale(amax, old_scale, ent.scaled_max);
 }
 
 AmaxAlgo parse_algo(const char *s) {
@@ -229,11 +230,12 @@ AmaxAlgo parse_algo(const char *s) {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// `dtypes` == nullptr: every tensor has format `fp8_dtype` (the reference's call); else one format per tensor
 void after_reduction_impl(const NVTETensor reduced_h, const NVTETensor *hists,
                           const NVTETensor *scales, size_t n, const char *algo_s, NVTEDType fp8_dtype,
-                          float margin, hipStream_t stream) {
+                          float margin, hipStream_t stream, const NVTEDType *dtypes = nullptr) {
   const AmaxAlgo algo = parse_algo(algo_s);
-  const float scaled_max = fp8_max_of(fp8_dtype) * std::pow(2.f, -margin);
+  const float margin_mult = std::pow(2.f, -margin);
   const Tensor &reduced = *lookup_checked(reduced_h);
   const float *buf = static_cast<const float *>(reduced.data.ptr);
   size_t length = 0;
@@ -263,14 +265,14 @@ void after_reduction_impl(const NVTETensor reduced_h, const NVTETensor *hists,
       NVTE_CHECK(s->data.shape.ndim == 1, "Found ", s->data.shape.ndim, " dims");
       NVTE_CHECK(s->data.numel() == static_cast<size_t>(ns), "Expected ", ns, " elements, Found ",
                  s->data.numel(), ".");
-      p.e[k] = BulkEntry{static_cast<float *>(h->data.ptr), static_cast<float *>(s->data.ptr), ns,
-                         offset};
+      p.e[k] = BulkEntry{static_cast<float *>(h->data.ptr), static_cast<float *>(s->data.ptr), ns, offset,
+                         fp8_max_of(dtypes ? dtypes[done + k] : fp8_dtype) * margin_mult};
       offset += ns;
       max_scales = std::max(max_scales, ns);
     }
     if (max_scales > 0 && length > 0) {
       hipLaunchKernelGGL(delayed_scaling_bulk_kernel, dim3(cnt, max_scales), dim3(kDsThreads), 0,
-                         stream, buf, p, length, algo, scaled_max);
+                         stream, buf, p, length, algo);
       NVTE_CHECK_HIP(hipGetLastError());
     }
     done += cnt;
@@ -458,6 +460,19 @@ void nvte_amd_delayed_scaling_after_reduction(const NVTETensor amax_reduction_bu
   api_guard("nvte_amd_delayed_scaling_after_reduction", [&] {
     after_reduction_impl(amax_reduction_buffer, amax_histories, scales, num_tensors,
                          amax_compute_algo, fp8_dtype, margin, stream);
+  });
+}
+
+void nvte_amd_delayed_scaling_after_reduction_multi(const NVTETensor amax_reduction_buffer,
+                                                    const NVTETensor *amax_histories,
+                                                    const NVTETensor *scales,
+                                                    const NVTEDType *fp8_dtypes, size_t num_tensors,
+                                                    const char *amax_compute_algo, float margin,
+                                                    hipStream_t stream) {
+  api_guard("nvte_amd_delayed_scaling_after_reduction_multi", [&] {
+    NVTE_CHECK(num_tensors == 0 || fp8_dtypes != nullptr, "fp8_dtypes must hold one entry per tensor");
+    after_reduction_impl(amax_reduction_buffer, amax_histories, scales, num_tensors, amax_compute_algo,
+                         kNVTEFloat8E4M3, margin, stream, fp8_dtypes);
   });
 }
 

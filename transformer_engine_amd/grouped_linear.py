@@ -9,6 +9,10 @@ grouped GEMM per pass, ``m_splits`` never leaves the GPU.
   backward  dY --group_quantize(row+col, E5M2 under HYBRID)--> dY8
             dX_i = dY8_i W8_i                       grouped GEMM "NN"
             dW_i = dY8_i^T X8_i (+ main_grad_i)     grouped GEMM "NT", discrete outputs
+
+Recipes: current scaling, MXFP8 and delayed scaling (one scale / amax history per expert and operand).  The
+reference's legacy path (host ``m_splits``, ``tex.split_quantize``, list GEMM; :630-697) is mirrored by
+``grouped_linear_forward_list`` / ``grouped_linear_backward_list`` over the SAME recipe state.
 """
 from __future__ import annotations
 
@@ -18,8 +22,9 @@ import torch
 
 from .grouped import (GroupedTensor, general_grouped_gemm_for_grouped_tensor, group_quantize,
                       splits_to_offsets)
-from .recipe import Float8CurrentScaling, MXFP8BlockScaling, get_fp8_te_dtype
-from .tensor import Float8CurrentScalingQuantizer, MXFP8Quantizer
+from .recipe import (DelayedScaling, DelayedScalingRecipeState, Float8CurrentScaling, MXFP8BlockScaling,
+                     get_fp8_te_dtype, reduce_and_update_fp8_tensors)
+from .tensor import Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantizer
 
 
 class GroupedLinearFP8State:
@@ -37,10 +42,41 @@ class GroupedLinearFP8State:
                 q = MXFP8Quantizer(dt, columnwise_transposed=True)
                 q.optimize_for_gemm = True
                 return q
+        elif isinstance(recipe, DelayedScaling):
+            # One scale / amax-history column PER EXPERT and operand, as the reference's GroupedLinear keeps them
+            # (ref module/grouped_linear.py: num_gemms x {input, weight, output} forward quantizers, num_gemms x
+            # {grad_output, grad_input} backward ones).  Laid out [inputs G | weights G] so that a grouped quantizer
+            # sees its G scales / amaxes as one contiguous vector (nvte_group_quantize reads scale[i] per member).
+            G = num_gemms
+            self.fwd_state = DelayedScalingRecipeState(recipe, mode="forward", num_quantizers=2 * G, device=self.device)
+            self.bwd_state = DelayedScalingRecipeState(recipe, mode="backward", num_quantizers=G, device=self.device)
+            fs, bs = self.fwd_state, self.bwd_state
+            self.q_input = Float8Quantizer(fs.scale[:G], fs.amax_history[0][:G], f)
+            self.q_weight = Float8Quantizer(fs.scale[G:], fs.amax_history[0][G:], f)
+            self.q_grad = Float8Quantizer(bs.scale, bs.amax_history[0], b)
+            self.weight_cache = None
+            return
         else:
-            raise NotImplementedError("the grouped path implements FP8 current scaling and MXFP8")
+            raise NotImplementedError(f"GroupedLinear: recipe {type(recipe).__name__} is not implemented")
+        self.fwd_state = self.bwd_state = None
         self.q_input, self.q_weight, self.q_grad = mk(f), mk(f), mk(b)
         self.weight_cache: Optional[GroupedTensor] = None
+
+    def member_quantizers(self, which: str):
+        """Per-expert quantizers over the same recipe state, for the list path (split_quantize): expert i gets views
+        of scale[i] / amax[i] under delayed scaling, a quantizer of its own otherwise."""
+        q = {"input": self.q_input, "weight": self.q_weight, "grad": self.q_grad}[which]
+        if isinstance(q, Float8Quantizer):
+            return [Float8Quantizer(q.scale[i:i + 1], q.amax[i:i + 1], q.dtype) for i in range(self.num_gemms)]
+        return [q.copy() for _ in range(self.num_gemms)]
+
+    def update_fwd(self, group=None):
+        if self.fwd_state is not None:
+            reduce_and_update_fp8_tensors([self.fwd_state], group)
+
+    def update_bwd(self, group=None):
+        if self.bwd_state is not None:
+            reduce_and_update_fp8_tensors([self.bwd_state], group)
 
 
 def _hp_out(first_dims: torch.Tensor, rows: int, cols: int, G: int, dtype) -> GroupedTensor:
@@ -86,6 +122,75 @@ def grouped_linear_backward(dy: torch.Tensor, saved, first_dims: torch.Tensor, s
         accumulate_wgrad = False
     general_grouped_gemm_for_grouped_tensor(x8, dy8, wgrad_out, layout="NT", accumulate=accumulate_wgrad)
     return dx.rowwise_data.view(dy.shape[0], K), wgrad_out
+
+
+# ---------------------------------------------------------------------------------------
+# legacy list path (ref module/grouped_linear.py:630-697, the reference's default when
+# NVTE_GROUPED_LINEAR_USE_FUSED_GROUPED_GEMM is unset): host-side m_splits, tex.split_quantize into a
+# list of per-expert FP8 tensors, nvte_multi_tensor_gemm over the lists
+# ---------------------------------------------------------------------------------------
+def split_quantize(tensor: torch.Tensor, m_splits: List[int], quantizers) -> list:
+    """ref pytorch/csrc/extensions/cast.cpp (tex.split_quantize): rows [sum m_i, K] cut along dim 0, piece i
+    quantized with quantizers[i] (an empty piece gives an empty FP8 tensor)."""
+    if len(m_splits) != len(quantizers):
+        raise ValueError("split_quantize needs one quantizer per split")
+    if sum(m_splits) != tensor.shape[0]:
+        raise ValueError(f"splits sum to {sum(m_splits)}, the tensor has {tensor.shape[0]} rows")
+    outs, r0 = [], 0
+    for m, q in zip(m_splits, quantizers):
+        piece = tensor[r0:r0 + m]
+        outs.append(q(piece) if m else q.make_empty(piece.shape, dtype=tensor.dtype, device=tensor.device))
+        r0 += m
+    return outs
+
+
+def grouped_linear_forward_list(x: torch.Tensor, weights: List[torch.Tensor], m_splits: List[int],
+                                st: GroupedLinearFP8State, *, is_first_microbatch: Optional[bool] = None,
+                                needs_backward: bool = True):
+    """Legacy path forward: returns (y [sum m_i, N], saved)."""
+    from .gemm import general_grouped_gemm
+    G = st.num_gemms
+    qi, qw = st.member_quantizers("input"), st.member_quantizers("weight")
+    for q in qi + qw:
+        q.set_usage(rowwise=True, columnwise=needs_backward)
+    x8 = split_quantize(x.reshape(-1, x.shape[-1]), m_splits, qi)
+    cache = getattr(st, "weight_list_cache", None)
+    if cache is None or is_first_microbatch is None or is_first_microbatch:
+        w8 = [qw[i](weights[i]) for i in range(G)]
+        if is_first_microbatch is not None:
+            st.weight_list_cache = w8
+    else:
+        w8 = cache
+    N = weights[0].shape[0]
+    y = torch.empty(sum(m_splits), N, dtype=x.dtype, device=x.device)
+    live = [i for i in range(G) if m_splits[i] > 0]
+    if live:
+        outs = list(torch.split(y, list(m_splits), dim=0))
+        general_grouped_gemm([w8[i] for i in live], [x8[i] for i in live], [outs[i] for i in live], x.dtype, layout="TN")
+    return y, (x8, w8, list(m_splits))
+
+
+def grouped_linear_backward_list(dy: torch.Tensor, saved, st: GroupedLinearFP8State):
+    """Legacy path backward: returns (dx [sum m_i, K], list of dW_i [N, K]; an empty expert's dW is zero)."""
+    from .gemm import general_grouped_gemm
+    x8, w8, m_splits = saved
+    G = st.num_gemms
+    qg = st.member_quantizers("grad")
+    for q in qg:
+        q.set_usage(rowwise=True, columnwise=True)
+    dy8 = split_quantize(dy.reshape(-1, dy.shape[-1]), m_splits, qg)
+    N, K = w8[0].shape
+    dx = torch.empty(sum(m_splits), K, dtype=dy.dtype, device=dy.device)
+    dws = [torch.zeros(N, K, dtype=dy.dtype, device=dy.device) if m_splits[i] == 0 else
+           torch.empty(N, K, dtype=dy.dtype, device=dy.device) for i in range(G)]
+    live = [i for i in range(G) if m_splits[i] > 0]
+    if live:
+        dxs = list(torch.split(dx, list(m_splits), dim=0))
+        general_grouped_gemm([w8[i] for i in live], [dy8[i] for i in live], [dxs[i] for i in live], dy.dtype,
+                             layout="NN", grad=True)
+        general_grouped_gemm([x8[i] for i in live], [dy8[i] for i in live], [dws[i] for i in live], dy.dtype,
+                             layout="NT", grad=True)
+    return dx, dws
 
 
 class _GroupedLinearFn(torch.autograd.Function):

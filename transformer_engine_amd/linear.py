@@ -110,6 +110,16 @@ class LinearFP8State:
         if self.bwd_state is not None:
             reduce_and_update_fp8_tensors([self.bwd_state], group)
 
+    def update_fwd_bwd(self, group=None):
+        """Both directions' recipe step in ONE launch (and one packed amax all-reduce), behind the backward
+        pass.  The reference steps the forward states when the outermost autocast exits and the backward
+        states after the backward pass (ref pytorch/quantization.py:646-701); the two states of a layer are
+        independent and the forward scales are first read by the NEXT forward pass, so the values are those
+        of the two separate calls (tests/test_linear_gpu.py)."""
+        states = [s for s in (self.fwd_state, self.bwd_state) if s is not None]
+        if states:
+            reduce_and_update_fp8_tensors(states, group)
+
 
 def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                    st: LinearFP8State, *, is_first_microbatch: Optional[bool] = None,

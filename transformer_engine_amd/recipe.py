@@ -108,9 +108,15 @@ def fused_amax_and_scale_update_after_reduction(amax_reduction_buffer: torch.Ten
     H = (C.c_void_p * n)(*[w.handle for w in whs])
     S = (C.c_void_p * n)(*[w.handle for w in wss])
     try:
-        api.nvte_amd_delayed_scaling_after_reduction(wb.handle, H, S, n, amax_compute_algo.encode(),
-                                                     int(fp8_dtype), float(margin),
-                                                     current_stream_ptr())
+        if isinstance(fp8_dtype, (list, tuple)):
+            # one format per tensor (amd_ext.h): forward and backward states of a step in one launch
+            D = (C.c_int * n)(*[int(d) for d in fp8_dtype])
+            api.nvte_amd_delayed_scaling_after_reduction_multi(wb.handle, H, S, D, n, amax_compute_algo.encode(),
+                                                               float(margin), current_stream_ptr())
+        else:
+            api.nvte_amd_delayed_scaling_after_reduction(wb.handle, H, S, n, amax_compute_algo.encode(),
+                                                         int(fp8_dtype), float(margin),
+                                                         current_stream_ptr())
     finally:
         for w in [wb] + whs + wss:
             w.destroy()
@@ -136,9 +142,10 @@ def reduce_and_update_fp8_tensors(states: List[DelayedScalingRecipeState], group
             contiguous_amax.copy_(host)
         else:
             dist.all_reduce(contiguous_amax, op=dist.ReduceOp.MAX, group=group)
+    dtypes = [s.dtype for s in states]
     fused_amax_and_scale_update_after_reduction(
         contiguous_amax, [s.amax_history for s in states], [s.scale for s in states],
-        recipe.amax_compute_algo, states[0].dtype, recipe.margin)
+        recipe.amax_compute_algo, dtypes[0] if all(d == dtypes[0] for d in dtypes) else dtypes, recipe.margin)
 
 
 def make_quantizers(recipe, *, mode: str, num_quantizers: int, device=None):
