@@ -47,12 +47,17 @@ def parse():
     ap.add_argument("--in-features", type=int, default=4096)
     ap.add_argument("--out-features", type=int, default=14336)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--parallelism", choices=["dp", "tp_sp"], default="dp")
+    ap.add_argument("--parallelism", choices=["dp", "tp_sp", "ep"], default="dp",
+                    help="dp: N replicas of the configs[1] step (default); tp_sp: sharded layers (configs[3] pattern); "
+                         "ep: configs[4], 8 experts spread over the ranks, no collective inside the path")
     ap.add_argument("--tp-layer", choices=["column", "row", "ln_column"], default="column",
                     help="tp_sp: column-parallel Linear (default), row-parallel Linear, or column-parallel LayerNormLinear (configs[3])")
     ap.add_argument("--tp-chunks", type=int, default=2, help="tp_sp: pieces the AG+GEMM / GEMM+RS pipelines are cut into")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse on one device)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--gemm-cus", type=int, default=0,
+                    help="cap the persistent GEMM grid at this many CUs (NVTE_EXT_MARGIN_SM of the reference: the rest is "
+                         "left to the RCCL kernels of an overlapped step); 0 = all")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grouped", action="store_true", help="skip the configs[4]-shaped GroupedLinear side measurement")
     return ap.parse_args()
@@ -212,8 +217,44 @@ def main():
     M, K, N = args.tokens, args.in_features, args.out_features
     torch.manual_seed(1234 + rank)
     recipe = DelayedScaling()   # HYBRID, history 1024, "max", margin 0 (reference defaults)
+    if args.gemm_cus > 0:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        os.environ["NVTE_EXT_MARGIN_SM"] = str(max(cus - args.gemm_cus, 0))
 
-    if world == 1 or args.parallelism == "dp":
+    ep_info = None
+    if args.parallelism == "ep":
+        # BASELINE configs[4]: Mixtral 8x7B GroupedLinear, expert-parallel.  The 8 experts are spread over the ranks
+        # (8 / N each); a rank sees the routed tokens of ITS experts (fixed-seed ragged splits of 8192 tokens x top-2,
+        # padded to 16 rows) already dispatched - the all-to-all belongs to the MoE layer around GroupedLinear, nothing
+        # inside this path communicates.  Total work is fixed as N grows: "strong" scaling.
+        import numpy as np
+        from transformer_engine_amd.grouped_linear import (GroupedLinearFP8State, grouped_linear_backward,
+                                                           grouped_linear_forward)
+        from transformer_engine_amd.recipe import Float8CurrentScaling
+        E, routed = 8, 16384
+        if E % world != 0:
+            raise SystemExit("--parallelism ep needs a rank count that divides the 8 experts")
+        counts = np.bincount(np.random.default_rng(1234).integers(0, E, size=routed), minlength=E)
+        all_splits = [int((c + 15) // 16 * 16) for c in counts]
+        G = E // world
+        m_splits = all_splits[rank * G:(rank + 1) * G]
+        Mr = sum(m_splits)
+        x = torch.randn(Mr, K, device=dev, dtype=torch.bfloat16)
+        w = torch.randn(G * N, K, device=dev, dtype=torch.bfloat16) * 0.02
+        dy = torch.randn(Mr, N, device=dev, dtype=torch.bfloat16)
+        fd = torch.tensor(m_splits, dtype=torch.int64, device=dev)
+        gst = GroupedLinearFP8State(Float8CurrentScaling(), G, dev)
+        grads = [torch.zeros(N, K, device=dev, dtype=torch.bfloat16) for _ in range(G)]
+
+        def step(first=False):
+            y, saved = grouped_linear_forward(x, w, fd, gst, is_first_microbatch=first)
+            return grouped_linear_backward(dy, saved, fd, gst, wgrad_out=grads, accumulate_wgrad=False)
+
+        flops_per_step = 6.0 * sum(all_splits) * N * K          # whole job
+        parallelism = f"ep{world} ({G} experts per rank)"
+        global_tokens = sum(all_splits)
+        ep_info = {"experts": E, "experts_per_rank": G, "m_splits_all": all_splits}
+    elif world == 1 or args.parallelism == "dp":
         x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
         dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
@@ -262,7 +303,8 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    use_graph = (not args.no_graph) and world == 1   # RCCL collectives are left out of graph capture
+    # RCCL collectives are left out of graph capture; the expert-parallel step has none (per-rank graph)
+    use_graph = (not args.no_graph) and (world == 1 or args.parallelism == "ep")
     graph = None
     seg = None
     if (not args.no_graph) and world > 1 and args.parallelism == "dp":
@@ -375,6 +417,18 @@ def main():
                       if seg is not None else {})},
         "tflops_per_gpu": tflops / world,
     }
+    if ep_info is not None:
+        result["scaling"] = "strong"
+        result["dtype"] = "fp8(e4m3/e5m2)->f32acc"
+        result["config"] = {"workload": "BASELINE configs[4]: Mixtral 8x7B GroupedLinear 4096->14336, 8 experts, 16384 routed "
+                                        "tokens (8192 x top-2, ragged splits padded to 16), per-expert FP8 current scaling "
+                                        "quantize + grouped FP8 GEMM, fwd+bwd; experts spread over the ranks, tokens "
+                                        "already dispatched (no collective inside the path)",
+                            "routed_tokens": global_tokens, "in_features": K, "out_features": N, "parallelism": parallelism,
+                            "hip_graph": graph is not None, "weight_quantize": "amortised (is_first_microbatch=False)",
+                            **ep_info}
+    if args.gemm_cus > 0:
+        result["config"]["gemm_cus"] = args.gemm_cus
 
     if world > 1 and args.parallelism == "tp_sp":
         # ---- exposed communication: the same step (a) with the pipelines switched off (one blocking
@@ -420,7 +474,7 @@ def main():
                                          "reduce_scatter_bf16": rs_src.numel() * 2 * (world - 1) // world}
         result["config"]["tp_chunks"] = args.tp_chunks
 
-    if world == 1 or args.parallelism == "dp":
+    if (world == 1 or args.parallelism == "dp") and args.parallelism != "ep":
         # ---- per-kernel measurements (HIP events on the launch stream) -------------------------
         # every rank runs them (the instrumented steps contain the recipe's amax all-reduce); rank 0 reports
         from transformer_engine_amd import general_gemm

@@ -64,3 +64,23 @@ def test_mxfp8_states_pick_the_scale_layout_like_the_reference_modules():
     assert not st.bwd_q[L.BWD_GRAD_OUTPUT].optimize_for_gemm and st.fwd_q[L.FWD_INPUT].optimize_for_gemm
     g = GroupedLinearFP8State(MXFP8BlockScaling(), 4, cpu)
     assert g.q_input.optimize_for_gemm and g.q_weight.optimize_for_gemm and g.q_grad.optimize_for_gemm
+
+
+def test_wrap_plain_handles_are_read_only():
+    """wrap_plain hands every caller the SAME cached handle for one (address, dtype, shape): a setter through
+    one reference would silently change it under every other holder (ADVICE r2), so setters are refused."""
+    from transformer_engine_amd import tensor as T
+    import inspect
+    src = inspect.getsource(T._PlainRef.__getattr__)
+    assert "set_" in src and "clear_" in src
+
+    class _W:
+        handle = 1
+        def set_amax(self, *a): raise AssertionError("reached the shared handle")
+        def shape(self): return (2, 3)
+    ref = T._PlainRef(_W(), None)
+    assert ref.shape() == (2, 3)
+    with pytest.raises(AttributeError, match="read-only"):
+        ref.set_amax(None)
+    with pytest.raises(AttributeError, match="read-only"):
+        ref.clear_amax()

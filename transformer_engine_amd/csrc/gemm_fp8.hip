@@ -1486,9 +1486,10 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
 }
 
 // records | tile prefix + the 9 XCD run boundaries | MXFP8 scale records (+ 256 to align the caller's pointer)
-size_t group_prefix_bytes(size_t G) { return round_up((G + 1 + 9) * sizeof(unsigned), 256); }
-size_t grouped_setup_bytes(size_t G) {
-  return round_up(G * sizeof(GroupDesc), 256) + group_prefix_bytes(G) + round_up(G * sizeof(GroupScaleDesc), 256) + 256;
+constexpr size_t cround_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+constexpr size_t group_prefix_bytes(size_t G) { return cround_up((G + 1 + 9) * sizeof(unsigned), 256); }
+constexpr size_t grouped_setup_bytes(size_t G) {
+  return cround_up(G * sizeof(GroupDesc), 256) + group_prefix_bytes(G) + cround_up(G * sizeof(GroupScaleDesc), 256) + 256;
 }
 
 // Pick the K-contiguous storage of an FP8 grouped operand ("TN everywhere", like the ungrouped path
@@ -1802,16 +1803,19 @@ void multi_gemm_impl(const NVTETensor *A, const NVTETensor *B, NVTETensor *D, co
 // holds its own copy (about 26 KiB) until the process ends.  The array's name is a host-side stand-in:
 // host code only ever uses the per-device address obtained below.
 constexpr size_t kNoAllocMaxGroups = 256;
-constexpr size_t kNoAllocScratchBytes = 256 * 64 /* GroupDesc records */ + 1280 /* tile prefix, 257 x 4 rounded up */ +
-                                        256 * 32 /* GroupScaleDesc records */ + 256 + 256;
-static_assert(sizeof(GroupDesc) <= 64 && sizeof(GroupScaleDesc) <= 32, "resize kNoAllocScratchBytes");
+// = what nvte_get_grouped_gemm_setup_workspace_size() asks a caller for: GroupDesc records, tile prefix
+// ((G + 1) tile starts + 9 XCD run boundaries, 4 bytes each), GroupScaleDesc records, 256 to align the base
+constexpr size_t kNoAllocScratchBytes = grouped_setup_bytes(kNoAllocMaxGroups);
+static_assert(kNoAllocScratchBytes <= 32 * 1024, "the static scratch array is meant to stay modest");
 static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
 
 constexpr int kMaxDevices = 64;
 std::mutex scratch_mu;
 void *scratch_ptr_of_device[kMaxDevices] = {};
 
-// Device address of `scratch` on the CURRENT device (looked up once per device).
+// Device address of `scratch` on the CURRENT device (looked up once per device).  The caller's stream must
+// belong to the current device, as for every other entry point of this library (kernels are launched on
+// `stream` with pointers of the current device; HIP rejects a launch on another device's stream).
 void *scratch_ptr() {
   int dev = 0;
   NVTE_CHECK_HIP(hipGetDevice(&dev));
@@ -1866,7 +1870,7 @@ void nvte_amd_grouped_gemm_noalloc(const NVTEGroupedTensor A, int transa, const 
     const size_t G = call.A->num_tensors;
     NVTE_CHECK(G <= kNoAllocMaxGroups, "nvte_amd_grouped_gemm_noalloc: ", G, " member tensors exceed the static scratch "
                "limit of ", kNoAllocMaxGroups, "; use nvte_grouped_gemm with a caller workspace");
-    static_assert(kNoAllocScratchBytes >= 256 * 64 + 1280 + 256 * 32 + 256 && kNoAllocMaxGroups == 256, "scratch too small");
+    static_assert(kNoAllocScratchBytes >= grouped_setup_bytes(kNoAllocMaxGroups), "scratch too small");
     // Nothing in the scratch has to start at zero: grouped_setup_kernel rewrites every record and
     // prefix entry of this call's G members before the GEMM kernel (same stream) reads them.
     grouped_gemm_impl("nvte_amd_grouped_gemm_noalloc", call, G, transa != 0, transb != 0, alpha, beta,

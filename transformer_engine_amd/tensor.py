@@ -11,6 +11,7 @@ runs in the HIP library through the C ABI.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import enum
 from typing import Optional, Sequence, Tuple
 
@@ -177,6 +178,7 @@ class _CachedWrapper(TensorWrapper):
 
 
 _PLAIN = {}          # (data_ptr, dtype, shape) -> handle: a descriptor of that memory, whoever owns it now
+_PLAIN_LOCK = threading.Lock()
 _PLAIN_MAX = 512
 
 
@@ -191,11 +193,12 @@ def wrap_plain(t: torch.Tensor) -> TensorWrapper:
     key = (t.data_ptr(), t.dtype, tuple(t.shape))
     w = _PLAIN.get(key)
     if w is None:
-        if len(_PLAIN) >= _PLAIN_MAX:
-            _PLAIN.pop(next(iter(_PLAIN)))
         w = _CachedWrapper()
         w._set(_lib.kRowwiseData, key[0], te_dtype(t.dtype), key[2])
-        _PLAIN[key] = w
+        with _PLAIN_LOCK:      # the autograd thread wraps too: evict and insert under one lock
+            while len(_PLAIN) >= _PLAIN_MAX:
+                _PLAIN.pop(next(iter(_PLAIN)), None)
+            _PLAIN[key] = w
     return _PlainRef(w, t)
 
 
@@ -212,6 +215,11 @@ class _PlainRef:
         self._t = None
 
     def __getattr__(self, name):          # getters of the underlying wrapper (shape(), get_param(), ...)
+        # the handle is SHARED by everybody who wraps the same (address, dtype, shape): a setter through one
+        # reference would change it under every other holder
+        if name.startswith(("set_", "clear_", "_set")):
+            raise AttributeError(f"wrap_plain() handles are shared and read-only: {name}() is not available; "
+                                 "build a TensorWrapper of your own")
         return getattr(self._w, name)
 
 
