@@ -67,6 +67,7 @@ def test_mxfp8_states_pick_the_scale_layout_like_the_reference_modules():
 
 
 def test_wrap_plain_handles_are_read_only():
+    import pytest
     """wrap_plain hands every caller the SAME cached handle for one (address, dtype, shape): a setter through
     one reference would silently change it under every other holder (ADVICE r2), so setters are refused."""
     from transformer_engine_amd import tensor as T
