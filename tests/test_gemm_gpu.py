@@ -246,13 +246,88 @@ def test_mxfp8_gemm_dgrad_wgrad_layouts(swizzled):
         assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max())
 
 
-def test_mxfp8_gemm_rejects_reference_columnwise_layout_loudly():
-    q = MXFP8Quantizer(E4)            # reference layout: columnwise payload not transposed
-    a = q(torch.randn(256, 256, device="cuda", dtype=torch.bfloat16))
-    b = q(torch.randn(256, 256, device="cuda", dtype=torch.bfloat16))
+@pytest.mark.parametrize("swizzled", [False, True])
+@pytest.mark.parametrize("M,N,K", [(384, 256, 512), (256, 256, 128), (1024, 768, 1536), (2048, 4352, 640), (288, 416, 96)])
+def test_mxfp8_gemm_reference_columnwise_layout_dgrad_wgrad(M, N, K, swizzled):
+    """MXFP8 NN (dgrad) and NT (wgrad) on the REFERENCE's columnwise layout: the payload keeps the tensor's own
+    [rows, cols] shape, quantized along the rows, scales [pad4(rows/32), pad128(cols)] (ref cublaslt_gemm.cu:179-193,
+    :268-278 hands it to cuBLASLt as a non-TN operand).  The kernel reads it K-major through ds_read_b64_tr_b8.
+      * oracle: matmul of the dequantized columnwise-quantized operands (oracle.mxfp8), fp32 output tolerance
+        rtol 1e-3 / atol 1e-3 of absmax (FP8 MFMA internal precision);
+      * bit-equal to the same GEMM fed the transposed-columnwise extension layout (same tiles, same K order).
+    Shapes: one tile, several K tiles, multi-tile with ragged edges (288 x 416 x 96: partial tiles on every side, K tails)."""
+    g = np.random.default_rng(7)
+    x = torch.from_numpy(g.standard_normal((M, K), dtype=np.float32)).cuda().to(torch.bfloat16)
+    w = torch.from_numpy(g.standard_normal((N, K), dtype=np.float32) * 0.05).cuda().to(torch.bfloat16)
+    dy = torch.from_numpy(g.standard_normal((M, N), dtype=np.float32) * 0.01).cuda().to(torch.bfloat16)
+    # per-row / per-column magnitudes differ, so a scale taken from the wrong row or block shows
+    dy *= (1.0 + torch.arange(M, device="cuda").remainder(7).to(torch.bfloat16))[:, None]
+    x *= (1.0 + torch.arange(K, device="cuda").remainder(5).to(torch.bfloat16))[None, :]
+
+    def mk(dt, transposed):
+        q = MXFP8Quantizer(dt, rowwise=True, columnwise=True, columnwise_transposed=transposed)
+        q.optimize_for_gemm = swizzled
+        return q
+    whole = M % 128 == 0 and N % 128 == 0 and K % 128 == 0
+    x8, w8, dy8 = mk(E4, False)(x), mk(E4, False)(w), mk(E5, False)(dy)
+    assert tuple(w8._columnwise_data.shape) == (N, K) and not w8._columnwise_transposed      # the reference layout
+    dx, *_ = general_gemm(w8, dy8, out_dtype=torch.float32, layout="NN", grad=True)
+    dw, *_ = general_gemm(x8, dy8, out_dtype=torch.float32, layout="NT", grad=True)
+    torch.cuda.synchronize()
+    bits = lambda t: oracle.float_to_bf16_bits(t.float().cpu().numpy())
+    rx, rw, rdy = oracle.mxfp8(bits(x), oracle.E4M3), oracle.mxfp8(bits(w), oracle.E4M3), oracle.mxfp8(bits(dy), oracle.E5M2)
+    fdy_r = oracle.dequant_mxfp8(rdy["out_row"], oracle.E5M2, rdy["sc_row"], True)
+    fw_c = oracle.dequant_mxfp8(rw["out_col"], oracle.E4M3, rw["sc_col"], False)
+    ref_dx = fdy_r.astype(np.float64) @ fw_c.astype(np.float64)
+    fdy_c = oracle.dequant_mxfp8(rdy["out_col"], oracle.E5M2, rdy["sc_col"], False)
+    fx_c = oracle.dequant_mxfp8(rx["out_col"], oracle.E4M3, rx["sc_col"], False)
+    ref_dw = fdy_c.astype(np.float64).T @ fx_c.astype(np.float64)
+    for name, got, ref in (("dgrad", dx, ref_dx), ("wgrad", dw, ref_dw)):
+        got = got.cpu().numpy().astype(np.float64)
+        assert got.shape == ref.shape
+        bad = np.abs(got - ref) > 1e-3 * np.abs(ref) + 1e-3 * np.abs(ref).max()
+        assert not bad.any(), (name, int(bad.sum()), np.argwhere(bad)[:4].tolist())
+    if whole:      # the transposed-columnwise extension needs whole 128 x 128 tiles
+        x8t, w8t, dy8t = mk(E4, True)(x), mk(E4, True)(w), mk(E5, True)(dy)
+        dxt, *_ = general_gemm(w8t, dy8t, out_dtype=torch.float32, layout="NN", grad=True)
+        dwt, *_ = general_gemm(x8t, dy8t, out_dtype=torch.float32, layout="NT", grad=True)
+        torch.cuda.synchronize()
+        assert torch.equal(dx, dxt) and torch.equal(dw, dwt)
+
+
+def test_mxfp8_gemm_reference_columnwise_layout_exact_integers():
+    """Small-integer payloads with power-of-two block scales: every product and sum is exact, so a fragment byte
+    taken from the wrong k or row of the K-major image shows as a mismatch.  Multi-tile (9 x 5 tiles), 5 K tiles."""
+    M, N, K = 1152, 2304, 640
+    g = np.random.default_rng(3)
+    xv = g.integers(-3, 4, size=(M, K)).astype(np.float32)
+    wv = g.integers(-3, 4, size=(N, K)).astype(np.float32)
+    dyv = g.integers(-3, 4, size=(M, N)).astype(np.float32)
+    # scale every 32-row block of the columnwise direction by a different power of two (exact in MXFP8)
+    xv *= (2.0 ** (np.arange(M) // 32 % 3))[:, None]
+    wv *= (2.0 ** (np.arange(N) // 32 % 4))[:, None]
+    dyv *= (2.0 ** (np.arange(M) // 32 % 2))[:, None]
+    q4, q5 = MXFP8Quantizer(E4), MXFP8Quantizer(E5)
+    x8, w8, dy8 = (q(torch.from_numpy(v).cuda().to(torch.bfloat16)) for q, v in ((q4, xv), (q4, wv), (q5, dyv)))
+    dx, *_ = general_gemm(w8, dy8, out_dtype=torch.float32, layout="NN", grad=True)
+    dw, *_ = general_gemm(x8, dy8, out_dtype=torch.float32, layout="NT", grad=True)
+    torch.cuda.synchronize()
+    ref_dx = torch.from_numpy(dyv).cuda().double() @ torch.from_numpy(wv).cuda().double()
+    ref_dw = torch.from_numpy(dyv).cuda().double().T @ torch.from_numpy(xv).cuda().double()
+    assert torch.equal(dx.double(), ref_dx)
+    assert torch.equal(dw.double(), ref_dw)
+
+
+def test_mxfp8_gemm_k_major_argument_errors():
+    """What the K-major path does not take is refused loudly, never computed wrongly."""
     from transformer_engine_amd._lib import NVTEError
-    with pytest.raises(NVTEError, match="transposed columnwise"):
-        general_gemm(a, b, out_dtype=torch.float32, layout="NN")
+    q, qt = MXFP8Quantizer(E4), MXFP8Quantizer(E4, columnwise_transposed=True)
+    a = q(torch.randn(256, 256, device="cuda", dtype=torch.bfloat16))
+    bt = qt(torch.randn(256, 256, device="cuda", dtype=torch.bfloat16))
+    with pytest.raises(NVTEError, match="K-major B operand"):
+        general_gemm(bt, a, out_dtype=torch.float32, layout="NT")     # A transposed layout, B reference layout
+    with pytest.raises(NVTEError, match="epilogues read K-contiguous"):
+        general_gemm(a, a, out_dtype=torch.float32, layout="NN", gelu=True)
 
 
 @pytest.mark.parametrize("M,N,K", [

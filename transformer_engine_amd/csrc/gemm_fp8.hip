@@ -69,6 +69,7 @@ struct GemmArgs {
   const uint8_t *eQ;
   unsigned n, m, k;
   unsigned ldd;
+  unsigned ldP, ldQ;              // K-MAJOR operands (kernel variant KM): bytes between consecutive k of one row
   unsigned eP_stride, eQ_stride;  // compact layout row stride (bytes)
   unsigned eP_swz, eQ_swz;        // 1 = GEMM-swizzled 128x4 tiles
   unsigned eP_bytes, eQ_bytes;    // size of the scale buffers
@@ -216,9 +217,16 @@ __device__ __forceinline__ void store_any(void *p, size_t idx, int dtype, float 
 //    two K tiles (the K tail is zero-filled anyway) so that the cross-tile pipeline is uniform.
 // ABL (diagnostic build only): ablations that keep the instruction stream's shape - 1: no global->LDS
 // staging in the main loop, 2: no LDS fragment reads, 3: neither (MFMA + barrier only).  Results are wrong.
-template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, bool EPI, bool GROUPED = false, int ABL = 0>
+// KM (bit 0: P, bit 1: Q): that operand is stored K-MAJOR - element (row, k) at k * ld + row, the layout of the
+// reference's un-transposed columnwise MXFP8 payload (ref cublaslt_gemm.cu:179-193, :268-278 hands it to cuBLASLt as a
+// non-TN operand).  LDS-DMA lays such a K tile down as [k][256 rows]; the MFMA fragments (8 consecutive k per lane
+// and read) come out of it through the transposing LDS load ds_read_b64_tr_b8.
+template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool MX, bool EPI, bool GROUPED = false, int ABL = 0,
+          int KM = 0>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   static_assert(!(GROUPED && EPI), "the grouped variant has no extended epilogues");
+  static_assert(KM == 0 || (MX && !GROUPED && !EPI), "K-major operands: plain MXFP8 kernel only");
+  constexpr bool PKM = (KM & 1) != 0, QKM = (KM & 2) != 0;
   // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
   constexpr int kScaleBase = 2 * kStageBytes;
   constexpr int kEpiBase = kScaleBase + (MX ? 2 * kScaleSlotBytes : 0);
@@ -368,11 +376,25 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     t.qbase = const_cast<uint8_t *>(a.Q) + static_cast<size_t>(t.j0) * a.k;
     t.pbytes = rows_p * a.k;
     t.qbytes = rows_q * a.k;
+    // K-major operand: the descriptor starts at the tile's first row inside k-row 0 and ends with the matrix, so
+    // k-rows past K read as zero; tile rows past the matrix end run into the next k-row (finite bytes that only
+    // feed output rows / columns which are never stored)
+    if constexpr (PKM) {
+      t.pbase = const_cast<uint8_t *>(a.P) + t.i0;
+      t.pbytes = valid ? a.k * a.ldP - t.i0 : 0u;
+    }
+    if constexpr (QKM) {
+      t.qbase = const_cast<uint8_t *>(a.Q) + t.j0;
+      t.qbytes = valid ? a.k * a.ldQ - t.j0 : 0u;
+    }
     if constexpr (MX) {
       // this wave stages the scales of tile rows (wave & 3) * 64 .. + 63 of P (waves 0-3) or Q (4-7)
       const unsigned tile_row0 = wave < 4 ? t.i0 : t.j0;
       t.ss = e_swz ? ((tile_row0 / 128 + ((wave & 3u) >> 1)) * (e_stride / 4)) * 512 + (wave & 1u) * 256
                    : (tile_row0 + (wave & 3u) * 64) * e_stride;
+      // compact scales of a K-major operand are stored [k block][row] (the reference's columnwise scale
+      // matrix): one 16-byte LDS-DMA instruction of wave 0 (P) / wave 4 (Q) brings the 4 x 256 bytes of a K tile
+      if ((wave < 4 ? PKM : QKM) && !e_swz) t.ss = tile_row0;
     }
     return t;
   };
@@ -389,7 +411,21 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     st_voff[q] = (lane >> 3) * a.k + c * 16;
     st_chunk_k[q] = c * 16;
   }
-  // two glds instructions (rows q*8.. of this wave's 32-row share of P and of Q)
+  // K-MAJOR operand: wave-instruction q fills k-rows (wave*4+q)*4 .. +3 of the [k][256 rows] image, lane ->
+  // (k row = lane >> 4, 16-byte unit = lane & 15).  The transposing fragment reads (below) touch, per LDS cycle, 8
+  // consecutive k-rows x 2 units x 2 halves: unit index XOR 2 * (k & 7) spreads them over all 64 banks; k & 7 only
+  // depends on (q & 1, lane), so two lane offsets serve the four instructions.
+  unsigned km_voffP[2] = {0, 0}, km_voffQ[2] = {0, 0};
+  if constexpr (KM != 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned kr = lane >> 4;
+      const unsigned u = (lane & 15u) ^ (static_cast<unsigned>(q) * 8u + 2u * kr);
+      km_voffP[q] = kr * a.ldP + u * 16;
+      km_voffQ[q] = kr * a.ldQ + u * 16;
+    }
+  }
+  // two glds instructions (rows q*8.. of this wave's 32-row share of P and of Q; K-major: k-rows q*4.. of its 16)
   auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
     uint8_t *base = lds + slot * kStageBytes;
     const unsigned soff = (wave * 4 + q) * 8 * (GROUPED ? t.k : a.k) + k0;
@@ -397,8 +433,16 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(t.qbase, 0, t.qbytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, kStageAux);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, kStageAux);
+    if constexpr (PKM)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, km_voffP[q & 1],
+                                               (k0 + (wave * 4 + q) * 4) * a.ldP, 0, kStageAux);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, kStageAux);
+    if constexpr (QKM)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, km_voffQ[q & 1],
+                                               (k0 + (wave * 4 + q) * 4) * a.ldQ, 0, kStageAux);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, kStageAux);
   };
   auto stage_voff = [&](const TileCtx &t, unsigned k0, unsigned(&voff)[2]) {
 #pragma unroll
@@ -435,9 +479,47 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // (operand register map of v_mfma_*_32x32x64_f8f6f4, measured on gfx950: a lane's first 16
   // bytes are K = 16*half + [0,16), its last 16 bytes K = 32 + 16*half + [0,16); the 32-element
   // block b takes its e8m0 scale from lane half b)
+  // K-major image: one ds_read_b64_tr_b8 hands lane l (16-lane group g = l >> 4, i = l & 15) the 8 bytes
+  // M[2b + (i >> 3)][i & 7], b = 0..7, of the 16 x 8 byte matrix formed by the 8-byte chunks that the 16 lanes of
+  // its group ADDRESS (measured on gfx950, scratch/tr8_probe.hip).  With supplier 2b + p pointed at k-row kbase + b,
+  // rows r0 + 8p .. + 7, lane i receives 8 consecutive k of row r0 + i: a quarter of an MFMA operand fragment.
+  // Group g covers rows 16 (g & 1) .. + 15 of the 32-row block with the K half h = g >> 1, as the MFMA wants
+  // them; four reads (k offsets 0, 8, 32, 40 from 64 ks + 16 h) build the 32-byte fragment.
+  unsigned kmP[4] = {0, 0, 0, 0}, kmQ[2] = {0, 0}, kmS = 0;
+  if constexpr (KM != 0) {
+    const unsigned g = lane >> 4, i = lane & 15u, b = i >> 1, pp = i & 1u, h = g >> 1;
+    const unsigned krow = 16u * h + b;                       // + 64 ks + {0, 8, 32, 40}
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const unsigned u = wi * 8u + static_cast<unsigned>(mi) * 2u + (g & 1u);
+      kmP[mi] = krow * 256u + ((u ^ (2u * b)) * 16u) + 8u * pp;
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const unsigned u = wj * 4u + static_cast<unsigned>(nj) * 2u + (g & 1u);
+      kmQ[nj] = BM * BK + krow * 256u + ((u ^ (2u * b)) * 16u) + 8u * pp;
+    }
+    // scale image [k block][256 rows] of a K tile: supplier 2b + p -> scale row b & 3, rows 16 (g & 1) + 8p .. + 7;
+    // the low dword of the result is then the lane's 4 block scales (rows: + 32 mi, operand: + 1024 for Q)
+    kmS = (b & 3u) * 256u + 16u * (g & 1u) + 8u * pp;
+  }
+  typedef int v2i_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) v2i_t lds_v2i;
+  // the four transposing reads of one fragment: k offsets 0, 8, 32, 40 (x 256 bytes per k-row) from `p0`
+  auto rd_tr8 = [&](const uint8_t *p0, v8i &f) {
+    const v2i_t r0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(p0));
+    const v2i_t r1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(p0 + 8 * 256));
+    const v2i_t r2 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(p0 + 32 * 256));
+    const v2i_t r3 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(p0 + 40 * 256));
+    f = v8i{r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+  };
   auto rdP = [&](unsigned slot, int ks, int mi, v8i &f) {
     if constexpr ((ABL & 2) != 0) { asm volatile("" : "+v"(f)); return; }
     const uint8_t *img = lds + slot * kStageBytes;
+    if constexpr (PKM) {
+      rd_tr8(img + kmP[mi] + ks * 64 * 256, f);
+      return;
+    }
     const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offP[2 * ks] + mi * 32 * BK);
     const u32x4 hi = *reinterpret_cast<const u32x4 *>(img + offP[2 * ks + 1] + mi * 32 * BK);
     f = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
@@ -445,6 +527,10 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   auto rdQ = [&](unsigned slot, int ks, int nj, v8i &f) {
     if constexpr ((ABL & 2) != 0) { asm volatile("" : "+v"(f)); return; }
     const uint8_t *img = lds + slot * kStageBytes;
+    if constexpr (QKM) {
+      rd_tr8(img + kmQ[nj] + ks * 64 * 256, f);
+      return;
+    }
     const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offQ[2 * ks] + nj * 32 * BK);
     const u32x4 hi = *reinterpret_cast<const u32x4 *>(img + offQ[2 * ks + 1] + nj * 32 * BK);
     f = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
@@ -488,8 +574,24 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       rsQstep = 128;
     }
   }
+  // this wave's operand is K-major with COMPACT scales ([k block][row], the reference's columnwise scale matrix)
+  const bool e_km = (wave < 4 ? PKM : QKM) && !e_swz;
+  // 4 scale rows x 256 tile rows of a K tile = one 16-byte-per-lane instruction of wave 0 (P) / wave 4 (Q):
+  // lane -> (scale row lane >> 4, rows 16 (lane & 15) .. + 15), lane-linear in LDS = the [k block][256] image.
+  // (A lambda of its own, outside every `if constexpr`: hipcc 7.2 silently drops the HOST stub of a kernel
+  // instantiation whose 16-byte LDS-DMA builtin sits in a branch that only some instantiations keep.)
+  auto stage_scales_km = [&](unsigned ss, unsigned slot, unsigned kt) {
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(e_base), 0, e_bytes, 0x00020000);
+    lds_u8 *dstk = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + (wave >> 2) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dstk, 16,
+                                             (lane >> 4) * e_stride + (lane & 15u) * 16u, ss + kt * 4u * e_stride, 0, 0);
+  };
   auto stage_scales = [&](const TileCtx &t, unsigned slot, unsigned kt) {
     if constexpr (MX) {
+      if (KM != 0 && e_km) {   // wave-uniform
+        if ((wave & 3u) == 0) stage_scales_km(t.ss, slot, kt);
+        return;
+      }
       const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<uint8_t *>(GROUPED ? t.eb : e_base), 0, GROUPED ? t.ebytes : e_bytes, 0x00020000);
       lds_u8 *dst = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + wave * 256);
@@ -512,12 +614,20 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       const uint32_t fill = 0x7F7F7F7Fu & ~keep;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        const uint32_t raw = *reinterpret_cast<const uint32_t *>(img + rsP0 + mi * rsPstep);
+        uint32_t raw;
+        if (PKM && !a.eP_swz)   // [k block][row] image: one transposing read = this lane's 4 block scales
+          raw = static_cast<uint32_t>(__builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(img + kmS + wi * 128 + mi * 32))[0]);
+        else
+          raw = *reinterpret_cast<const uint32_t *>(img + rsP0 + mi * rsPstep);
         scP[mi] = ((raw & keep) | fill) >> (8 * fr_half);
       }
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) {
-        const uint32_t raw = *reinterpret_cast<const uint32_t *>(img + rsQ0 + nj * rsQstep);
+        uint32_t raw;
+        if (QKM && !a.eQ_swz)
+          raw = static_cast<uint32_t>(__builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(img + 1024 + kmS + wj * 64 + nj * 32))[0]);
+        else
+          raw = *reinterpret_cast<const uint32_t *>(img + rsQ0 + nj * rsQstep);
         scQ[nj] = ((raw & keep) | fill) >> (8 * fr_half);
       }
     }
@@ -838,7 +948,9 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   stage_scales(cur_t, 0, 0);
   stage(cur_t, 1, BK);
   stage_scales(cur_t, 1, 1);
-  if constexpr (MX)
+  if constexpr (KM != 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the waves issue different numbers of scale loads here
+  else if constexpr (MX)
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -911,7 +1023,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
 #endif
 }
 
-template <bool MX, bool EPI, bool GROUPED = false>
+template <bool MX, bool EPI, bool GROUPED = false, int KM = 0>
 void launch_by_format(int fa, int fb, const GemmArgs &args_in, hipStream_t stream) {
 #ifdef TE_GEMM_STAMPS
   GemmArgs args = args_in;
@@ -935,7 +1047,7 @@ void launch_by_format(int fa, int fb, const GemmArgs &args_in, hipStream_t strea
 #endif
 #define TE_GEMM_CASE(A_, B_)                                                                       \
   if (fa == A_ && fb == B_) {                                                                      \
-    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX, EPI, GROUPED>), grid, block, 0, stream, args); \
+    hipLaunchKernelGGL((gemm_fp8_kernel<A_, B_, MX, EPI, GROUPED, 0, KM>), grid, block, 0, stream, args); \
     NVTE_CHECK_HIP(hipGetLastError());                                                             \
     return;                                                                                        \
   }
@@ -1000,6 +1112,8 @@ struct Operand {
   unsigned scale_stride = 0;
   size_t scale_bytes = 0;
   bool swizzled = false;
+  bool k_major = false;   // MXFP8 only: the reference's un-transposed columnwise payload, element (row, k) at k * ld + row
+  size_t ld = 0;
 };
 
 }  // namespace
@@ -1092,7 +1206,8 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     // Rowwise data is K-contiguous for a transposed A / non-transposed B.  The other layouts
     // contract over the stored rows: they need the columnwise-quantized copy in the transposed
     // layout of amd_ext.h (the MXFP8 twin of "non-TN FP8 GEMM unsupported -> keep a transpose").
-    auto pick = [](const Tensor &T, bool rowwise, const char *name) {
+    // `rows` = the operand's non-contracted extent (m for A, n for B)
+    auto pick = [](const Tensor &T, bool rowwise, const char *name, size_t rows) {
       Operand op;
       if (rowwise) {
         NVTE_CHECK(T.has_data(), "Input ", name, " is missing row-wise usage");
@@ -1103,23 +1218,40 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
         op.scale_bytes = T.scale_inv.numel();
       } else {
         NVTE_CHECK(T.has_columnwise_data(), "Input ", name, " is missing column-wise usage");
-        NVTE_CHECK(T.columnwise_transposed,
-                   "MXFP8 GEMM: this layout contracts over the stored rows of ", name,
-                   "; quantize it with the transposed columnwise layout "
-                   "(nvte_amd_set_columnwise_transposed) - the un-transposed columnwise payload is "
-                   "not readable by the gfx950 MFMA path");
         op.data = static_cast<const uint8_t *>(T.columnwise_data.ptr);
         op.dtype = T.columnwise_data.dtype;
         op.scale_inv = T.columnwise_scale_inv.ptr;
-        op.scale_stride =
-            static_cast<unsigned>(T.columnwise_scale_inv.shape.data[T.columnwise_scale_inv.shape.ndim - 1]);
+        const NVTEShape &ss = T.columnwise_scale_inv.shape;
         op.scale_bytes = T.columnwise_scale_inv.numel();
+        if (T.columnwise_transposed) {
+          // amd_ext.h layout: payload [rows, k], scales [pad128(rows), pad4(k / 32)] - K-contiguous like a rowwise operand
+          op.scale_stride = static_cast<unsigned>(ss.data[ss.ndim - 1]);
+        } else {
+          // the reference's layout (ref cublaslt_gemm.cu:179-193, :268-278: the columnwise payload keeps the tensor's own
+          // [k, rows] shape): K-MAJOR, read through the transposing LDS loads.  Compact scales [pad4(k / 32), pad128(rows)]
+          // are addressed by their row length; GEMM-swizzled ones have the one (row, k block) tile format whichever
+          // direction they were quantized in (ref common/swizzle/swizzle.cu), described by pad4(k / 32) blocks per row.
+          op.k_major = true;
+          op.ld = rows;
+          NVTE_CHECK(rows % 16 == 0, "MXFP8 GEMM: the un-transposed columnwise payload of ", name,
+                     " is read in 16-byte pieces along its last dimension (", rows, "), which must be a multiple of 16");
+          NVTE_CHECK(ss.ndim >= 2, "MXFP8 GEMM: columnwise scale_inv of ", name, " must be 2-D");
+          op.scale_stride = static_cast<unsigned>(T.with_gemm_swizzled_scales ? ss.data[ss.ndim - 2] : ss.data[ss.ndim - 1]);
+          NVTE_CHECK((reinterpret_cast<uintptr_t>(op.scale_inv) & 15u) == 0, "MXFP8 GEMM: columnwise scale_inv of ", name,
+                     " must be 16-byte aligned");
+        }
       }
       op.swizzled = T.with_gemm_swizzled_scales;
       return op;
     };
-    opA = pick(A, transa, "A");
-    opB = pick(B, !transb, "B");
+    opA = pick(A, transa, "A", m);
+    opB = pick(B, !transb, "B", n);
+    if (opA.k_major || opB.k_major) {
+      NVTE_CHECK(opA.k_major, "MXFP8 GEMM: a K-major B operand is implemented together with a K-major A only (the NT "
+                 "layout); quantize B with the transposed columnwise layout or A without it");
+      NVTE_CHECK(static_cast<unsigned long long>(k) * std::max(opA.ld, opB.ld) < (1ull << 32),
+                 "MXFP8 GEMM: K-major operand too large for 32-bit offsets");
+    }
     NVTE_CHECK(is_fp8(opA.dtype) && is_fp8(opB.dtype), "MXFP8 GEMM needs FP8 payloads");
     NVTE_CHECK(opA.scale_inv != nullptr && opB.scale_inv != nullptr,
                "FP8 input to GEMM requires inverse of scale!");
@@ -1161,6 +1293,8 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   g.m = static_cast<unsigned>(m);
   g.k = static_cast<unsigned>(k);
   g.ldd = static_cast<unsigned>(m);
+  g.ldP = static_cast<unsigned>(opB.ld);
+  g.ldQ = static_cast<unsigned>(opA.ld);
   g.alpha = alpha;
   g.beta = beta;
   g.d_dtype = D.data.dtype;
@@ -1206,7 +1340,12 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     }
   }
   const int fp = fmt_of(opB.dtype), fq = fmt_of(opA.dtype);
-  if (mx)
+  if (mx && (opA.k_major || opB.k_major)) {
+    NVTE_CHECK(!ext, "MXFP8 GEMM: the GELU / FP8-output epilogues read K-contiguous operands only; quantize with the "
+               "transposed columnwise layout (nvte_amd_set_columnwise_transposed) for this call");
+    opB.k_major ? launch_by_format<true, false, false, 3>(fp, fq, g, stream)
+                : launch_by_format<true, false, false, 2>(fp, fq, g, stream);
+  } else if (mx)
     ext ? launch_by_format<true, true>(fp, fq, g, stream) : launch_by_format<true, false>(fp, fq, g, stream);
   else
     ext ? launch_by_format<false, true>(fp, fq, g, stream) : launch_by_format<false, false>(fp, fq, g, stream);
@@ -1217,6 +1356,9 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     NVTE_CHECK_HIP(hipGetLastError());
   }
   if (bgradb) {
+    NVTE_CHECK(!opB.k_major, "MXFP8 GEMM: the bias-gradient side kernel sums a K-contiguous operand B; quantize B with "
+               "the transposed columnwise layout (nvte_amd_set_columnwise_transposed) or compute dbias in the quantize "
+               "(nvte_quantize_dbias)");
     // operand B as the kernel reads it: [n, k] K-contiguous
     const dim3 grid(static_cast<unsigned>(ceil_div(n, 4))), block(256);
     const float *sc = mx ? nullptr : static_cast<const float *>(opB.scale_inv);
