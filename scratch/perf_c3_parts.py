@@ -7,9 +7,11 @@ M = K = N = 8192
 x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
 w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
 dy = (torch.randn(M, N, device=dev) * 0.01).to(torch.bfloat16)
-for swz in (False, True):
+import itertools
+for swz, tr in itertools.product((False, True), (True, False)):
+    print(f"--- scales {'swizzled' if swz else 'compact'}, columnwise {'transposed (amd_ext)' if tr else 'reference (K-major reads)'}", flush=True)
     def mk(dt):
-        q = MXFP8Quantizer(dt, columnwise_transposed=True); q.optimize_for_gemm = swz; return q
+        q = MXFP8Quantizer(dt, columnwise_transposed=tr); q.optimize_for_gemm = swz; return q
     qx, qw, qg = mk(DType.kFloat8E4M3), mk(DType.kFloat8E4M3), mk(DType.kFloat8E5M2)
     for nm, q, t_ in (("qx", qx, x), ("qdy", qg, dy)):
         t = bench.time_kernel(lambda: q(t_), 20)

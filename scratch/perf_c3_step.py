@@ -9,8 +9,11 @@ M = K = N = 8192
 x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
 w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
 dy = (torch.randn(M, N, device=dev) * 0.01).to(torch.bfloat16)
-for name, st in 2 * (("mxfp8 swizzled", L.LinearFP8State(MXFP8BlockScaling(), device=dev)),
-                 ("mxfp8 compact", L.LinearFP8State(MXFP8BlockScaling(), device=dev, compact_mx_scales=("input", "weight", "grad_output"))),
+for name, st in 2 * (("mxfp8 swizzled, transposed columnwise (amd_ext)", L.LinearFP8State(MXFP8BlockScaling(), device=dev, mx_columnwise="transposed")),
+                 ("mxfp8 swizzled, reference columnwise (K-major GEMM reads)", L.LinearFP8State(MXFP8BlockScaling(), device=dev, mx_columnwise="reference")),
+                 ("mxfp8 swizzled, mixed (input + weight reference, grad_output transposed)", L.LinearFP8State(MXFP8BlockScaling(), device=dev, mx_columnwise="mixed")),
+                 ("mxfp8 compact, reference columnwise", L.LinearFP8State(MXFP8BlockScaling(), device=dev, mx_columnwise="reference", compact_mx_scales=("input", "weight", "grad_output"))),
+                 ("mxfp8 compact, transposed columnwise", L.LinearFP8State(MXFP8BlockScaling(), device=dev, mx_columnwise="transposed", compact_mx_scales=("input", "weight", "grad_output"))),
                  ("delayed", L.LinearFP8State(DelayedScaling(), device=dev))):
     L.linear_forward(x, w, None, st, is_first_microbatch=True)
     def step():

@@ -226,7 +226,11 @@ template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool M
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   static_assert(!(GROUPED && EPI), "the grouped variant has no extended epilogues");
   static_assert(KM == 0 || (MX && !GROUPED && !EPI), "K-major operands: plain MXFP8 kernel only");
-  constexpr bool PKM = (KM & 1) != 0, QKM = (KM & 2) != 0;
+  // bits 2 / 3: that K-major operand's e8m0 scales are COMPACT, i.e. stored [k block][row] like the payload (the
+  // reference's columnwise scale matrix); otherwise GEMM-swizzled, one format whatever the quantization direction.
+  // Compile-time on purpose: a run-time branch in the main loop lets the scheduler tear up the pinned MFMA order
+  // (measured: 300-430 spilled registers, 8x slower).
+  constexpr bool PKM = (KM & 1) != 0, QKM = (KM & 2) != 0, PKC = PKM && (KM & 4) != 0, QKC = QKM && (KM & 8) != 0;
   // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
   constexpr int kScaleBase = 2 * kStageBytes;
   constexpr int kEpiBase = kScaleBase + (MX ? 2 * kScaleSlotBytes : 0);
@@ -394,7 +398,9 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
                    : (tile_row0 + (wave & 3u) * 64) * e_stride;
       // compact scales of a K-major operand are stored [k block][row] (the reference's columnwise scale
       // matrix): one 16-byte LDS-DMA instruction of wave 0 (P) / wave 4 (Q) brings the 4 x 256 bytes of a K tile
-      if ((wave < 4 ? PKM : QKM) && !e_swz) t.ss = tile_row0;
+      // compact scales of a K-major operand, [k block][row]: wave w of the group stages scale ROW w of the K tile
+      // (256 bytes = one 4-byte-per-lane instruction, the shape of the other layouts' staging)
+      if (wave < 4 ? PKC : QKC) t.ss = tile_row0 + (wave & 3u) * e_stride;
     }
     return t;
   };
@@ -415,15 +421,14 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // (k row = lane >> 4, 16-byte unit = lane & 15).  The transposing fragment reads (below) touch, per LDS cycle, 8
   // consecutive k-rows x 2 units x 2 halves: unit index XOR 2 * (k & 7) spreads them over all 64 banks; k & 7 only
   // depends on (q & 1, lane), so two lane offsets serve the four instructions.
-  unsigned km_voffP[2] = {0, 0}, km_voffQ[2] = {0, 0};
+  // (instruction parity q & 1 flips bit 3 of the unit index: +-128 bytes, one lane constant for both operands)
+  unsigned km_voffP = 0, km_voffQ = 0, km_flip = 0;
   if constexpr (KM != 0) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const unsigned kr = lane >> 4;
-      const unsigned u = (lane & 15u) ^ (static_cast<unsigned>(q) * 8u + 2u * kr);
-      km_voffP[q] = kr * a.ldP + u * 16;
-      km_voffQ[q] = kr * a.ldQ + u * 16;
-    }
+    const unsigned kr = lane >> 4;
+    const unsigned u = (lane & 15u) ^ (2u * kr);
+    km_voffP = kr * a.ldP + u * 16;
+    km_voffQ = kr * a.ldQ + u * 16;
+    km_flip = (u & 8u) ? static_cast<unsigned>(-128) : 128u;
   }
   // two glds instructions (rows q*8.. of this wave's 32-row share of P and of Q; K-major: k-rows q*4.. of its 16)
   auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
@@ -434,13 +439,13 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(t.qbase, 0, t.qbytes, 0x00020000);
     if constexpr (PKM)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, km_voffP[q & 1],
-                                               (k0 + (wave * 4 + q) * 4) * a.ldP, 0, kStageAux);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16,
+                                               km_voffP + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldP, 0, kStageAux);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, kStageAux);
     if constexpr (QKM)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, km_voffQ[q & 1],
-                                               (k0 + (wave * 4 + q) * 4) * a.ldQ, 0, kStageAux);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16,
+                                               km_voffQ + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldQ, 0, kStageAux);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, kStageAux);
   };
@@ -485,20 +490,14 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // rows r0 + 8p .. + 7, lane i receives 8 consecutive k of row r0 + i: a quarter of an MFMA operand fragment.
   // Group g covers rows 16 (g & 1) .. + 15 of the 32-row block with the K half h = g >> 1, as the MFMA wants
   // them; four reads (k offsets 0, 8, 32, 40 from 64 ks + 16 h) build the 32-byte fragment.
-  unsigned kmP[4] = {0, 0, 0, 0}, kmQ[2] = {0, 0}, kmS = 0;
+  // The unit index of row block mi is wi * 8 + mi * 2 + (g & 1) (Q: wj * 4 + nj * 2 + (g & 1)): mi / nj sit in bits
+  // of their own, so the block's address is the lane's base XOR (mi << 5) - one lane register per operand.
+  unsigned kmP = 0, kmQ = 0, kmS = 0;
   if constexpr (KM != 0) {
     const unsigned g = lane >> 4, i = lane & 15u, b = i >> 1, pp = i & 1u, h = g >> 1;
     const unsigned krow = 16u * h + b;                       // + 64 ks + {0, 8, 32, 40}
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const unsigned u = wi * 8u + static_cast<unsigned>(mi) * 2u + (g & 1u);
-      kmP[mi] = krow * 256u + ((u ^ (2u * b)) * 16u) + 8u * pp;
-    }
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-      const unsigned u = wj * 4u + static_cast<unsigned>(nj) * 2u + (g & 1u);
-      kmQ[nj] = BM * BK + krow * 256u + ((u ^ (2u * b)) * 16u) + 8u * pp;
-    }
+    kmP = krow * 256u + (((wi * 8u + (g & 1u)) ^ (2u * b)) * 16u) + 8u * pp;
+    kmQ = BM * BK + krow * 256u + (((wj * 4u + (g & 1u)) ^ (2u * b)) * 16u) + 8u * pp;
     // scale image [k block][256 rows] of a K tile: supplier 2b + p -> scale row b & 3, rows 16 (g & 1) + 8p .. + 7;
     // the low dword of the result is then the lane's 4 block scales (rows: + 32 mi, operand: + 1024 for Q)
     kmS = (b & 3u) * 256u + 16u * (g & 1u) + 8u * pp;
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     if constexpr ((ABL & 2) != 0) { asm volatile("" : "+v"(f)); return; }
     const uint8_t *img = lds + slot * kStageBytes;
     if constexpr (PKM) {
-      rd_tr8(img + kmP[mi] + ks * 64 * 256, f);
+      rd_tr8(img + (kmP ^ (static_cast<unsigned>(mi) << 5)) + ks * 64 * 256, f);
       return;
     }
     const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offP[2 * ks] + mi * 32 * BK);
@@ -528,7 +527,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     if constexpr ((ABL & 2) != 0) { asm volatile("" : "+v"(f)); return; }
     const uint8_t *img = lds + slot * kStageBytes;
     if constexpr (QKM) {
-      rd_tr8(img + kmQ[nj] + ks * 64 * 256, f);
+      rd_tr8(img + (kmQ ^ (static_cast<unsigned>(nj) << 5)) + ks * 64 * 256, f);
       return;
     }
     const u32x4 lo = *reinterpret_cast<const u32x4 *>(img + offQ[2 * ks] + nj * 32 * BK);
@@ -558,7 +557,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   uint32_t scP[4] = {0, 0, 0, 0}, scQ[2] = {0, 0};
   unsigned sv = 0, rsP0 = 0, rsQ0 = 0, rsPstep = 0, rsQstep = 0;
   if constexpr (MX) {
-    sv = e_swz ? lane * 4 : lane * e_stride;
+    sv = (e_swz || (wave < 4 ? PKC : QKC)) ? lane * 4 : lane * e_stride;
     if (a.eP_swz) {
       rsP0 = wi * 512 + fr_row * 16;
       rsPstep = 4;
@@ -574,30 +573,21 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       rsQstep = 128;
     }
   }
-  // this wave's operand is K-major with COMPACT scales ([k block][row], the reference's columnwise scale matrix)
-  const bool e_km = (wave < 4 ? PKM : QKM) && !e_swz;
-  // 4 scale rows x 256 tile rows of a K tile = one 16-byte-per-lane instruction of wave 0 (P) / wave 4 (Q):
-  // lane -> (scale row lane >> 4, rows 16 (lane & 15) .. + 15), lane-linear in LDS = the [k block][256] image.
-  // (A lambda of its own, outside every `if constexpr`: hipcc 7.2 silently drops the HOST stub of a kernel
-  // instantiation whose 16-byte LDS-DMA builtin sits in a branch that only some instantiations keep.)
-  auto stage_scales_km = [&](unsigned ss, unsigned slot, unsigned kt) {
-    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(e_base), 0, e_bytes, 0x00020000);
-    lds_u8 *dstk = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + (wave >> 2) * 1024);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dstk, 16,
-                                             (lane >> 4) * e_stride + (lane & 15u) * 16u, ss + kt * 4u * e_stride, 0, 0);
-  };
+  // One 4-byte-per-lane LDS-DMA instruction per wave and K tile, whatever the layout (no branch in the main loop):
+  //   compact rowwise  : lane = tile row, source row * stride + 4 kt            -> LDS image [row] (dwords)
+  //   GEMM-swizzled    : 512-byte blocks of 128 rows, source + 512 kt
+  //   compact K-major  : wave w of the group = scale row w of the K tile, lane = 4 tile rows, source
+  //                      (4 kt + w) * stride + tile row 0 + 4 lane             -> LDS image [k block][256 rows]
+  const bool e_kc = wave < 4 ? PKC : QKC;
+  const unsigned e_step = e_swz ? 512u : (e_kc ? 4u * e_stride : 4u);
   auto stage_scales = [&](const TileCtx &t, unsigned slot, unsigned kt) {
     if constexpr (MX) {
-      if (KM != 0 && e_km) {   // wave-uniform
-        if ((wave & 3u) == 0) stage_scales_km(t.ss, slot, kt);
-        return;
-      }
       const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<uint8_t *>(GROUPED ? t.eb : e_base), 0, GROUPED ? t.ebytes : e_bytes, 0x00020000);
       lds_u8 *dst = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + wave * 256);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4,
                                                GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv,
-                                               t.ss + kt * (e_swz ? 512u : 4u), 0, 0);
+                                               t.ss + kt * e_step, 0, 0);
     }
   };
   // Pick this wave's scale dwords of K tile `kt` (already in scale slot `slot`) and pre-shift so
@@ -615,7 +605,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         uint32_t raw;
-        if (PKM && !a.eP_swz)   // [k block][row] image: one transposing read = this lane's 4 block scales
+        if constexpr (PKC)      // [k block][row] image: one transposing read = this lane's 4 block scales
           raw = static_cast<uint32_t>(__builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(img + kmS + wi * 128 + mi * 32))[0]);
         else
           raw = *reinterpret_cast<const uint32_t *>(img + rsP0 + mi * rsPstep);
@@ -624,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) {
         uint32_t raw;
-        if (QKM && !a.eQ_swz)
+        if constexpr (QKC)
           raw = static_cast<uint32_t>(__builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(img + 1024 + kmS + wj * 64 + nj * 32))[0]);
         else
           raw = *reinterpret_cast<const uint32_t *>(img + rsQ0 + nj * rsQstep);
@@ -948,9 +938,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   stage_scales(cur_t, 0, 0);
   stage(cur_t, 1, BK);
   stage_scales(cur_t, 1, 1);
-  if constexpr (KM != 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the waves issue different numbers of scale loads here
-  else if constexpr (MX)
+  if constexpr (MX)
     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -1343,8 +1331,16 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   if (mx && (opA.k_major || opB.k_major)) {
     NVTE_CHECK(!ext, "MXFP8 GEMM: the GELU / FP8-output epilogues read K-contiguous operands only; quantize with the "
                "transposed columnwise layout (nvte_amd_set_columnwise_transposed) for this call");
-    opB.k_major ? launch_by_format<true, false, false, 3>(fp, fq, g, stream)
-                : launch_by_format<true, false, false, 2>(fp, fq, g, stream);
+    // kernel variant: bit 0 / 1 = P / Q K-major, bit 2 / 3 = that operand's scales are compact ([k block][row])
+    const int km = (opB.k_major ? 1 : 0) | 2 | ((opB.k_major && !opB.swizzled) ? 4 : 0) | (!opA.swizzled ? 8 : 0);
+    switch (km) {
+      case 2: launch_by_format<true, false, false, 2>(fp, fq, g, stream); break;
+      case 10: launch_by_format<true, false, false, 10>(fp, fq, g, stream); break;
+      case 3: launch_by_format<true, false, false, 3>(fp, fq, g, stream); break;
+      case 7: launch_by_format<true, false, false, 7>(fp, fq, g, stream); break;
+      case 11: launch_by_format<true, false, false, 11>(fp, fq, g, stream); break;
+      default: launch_by_format<true, false, false, 15>(fp, fq, g, stream); break;
+    }
   } else if (mx)
     ext ? launch_by_format<true, true>(fp, fq, g, stream) : launch_by_format<true, false>(fp, fq, g, stream);
   else

@@ -16,6 +16,7 @@ Tensor/sequence parallel variants of the same sequence live in ``distributed.py`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
@@ -63,12 +64,21 @@ def bgrad_quantize(dy: torch.Tensor, quantizer):
     return dbias, out
 
 
+# which MXFP8 columnwise layout the module states ask the quantize kernels for (measured on the configs[2] step,
+# DESIGN 6c); both run through the same GEMM entry point
+MX_COLUMNWISE_DEFAULT = "transposed"
+
+
 class LinearFP8State:
     """Per-module quantization state: recipe states + quantizers for one Linear."""
 
-    def __init__(self, recipe, device=None, compact_mx_scales=()):
+    def __init__(self, recipe, device=None, compact_mx_scales=(), mx_columnwise: Optional[str] = None):
         """compact_mx_scales: which of "input", "weight", "grad_output" keep their MXFP8 scales in the compact
-        layout (the others are written GEMM-swizzled, see below)."""
+        layout (the others are written GEMM-swizzled, see below).
+        mx_columnwise: layout of the MXFP8 columnwise copies that dgrad / wgrad read - "reference" (the payload keeps
+        the tensor's own shape, what TE's MXFP8Tensor holds; the GEMM reads it K-major), "transposed" (the
+        amd_ext.h extension, K-contiguous) or "mixed" (reference for input and weight, transposed for grad_output);
+        default: NVTE_AMD_MX_COLUMNWISE, else MX_COLUMNWISE_DEFAULT."""
         self.recipe = recipe
         self.device = device or torch.device("cuda")
         self.fwd_state: Optional[DelayedScalingRecipeState] = None
@@ -87,9 +97,16 @@ class LinearFP8State:
             self.bwd_q = [mk(b) for _ in range(2)]
         elif isinstance(recipe, MXFP8BlockScaling):
             f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
-            # columnwise copies in the K-contiguous (transposed) layout the dgrad / wgrad GEMMs read
-            self.fwd_q = [MXFP8Quantizer(f, columnwise_transposed=True) for _ in range(3)]
-            self.bwd_q = [MXFP8Quantizer(b, columnwise_transposed=True) for _ in range(2)]
+            layout = mx_columnwise or os.environ.get("NVTE_AMD_MX_COLUMNWISE") or MX_COLUMNWISE_DEFAULT
+            if layout not in ("reference", "transposed", "mixed"):
+                raise ValueError(f"mx_columnwise must be 'reference', 'transposed' or 'mixed', got {layout!r}")
+            # "mixed": input and weight in the reference layout (each is the ONE K-major operand of its backward GEMM,
+            # which reads it at the K-contiguous rate), grad_output transposed (wgrad would otherwise read two K-major
+            # operands: twice the LDS read instructions, ~20 % slower)
+            tr_in = layout == "transposed"
+            tr_g = layout in ("transposed", "mixed")
+            self.fwd_q = [MXFP8Quantizer(f, columnwise_transposed=tr_in) for _ in range(3)]
+            self.bwd_q = [MXFP8Quantizer(b, columnwise_transposed=tr_g) for _ in range(2)]
             # Scales are written in the layout the GEMM reads (ref module/linear.py:2067-2078 for the input and
             # grad_output quantizers, module/base.py:1211-1229 for the weight), except where another consumer needs
             # the compact one: an all-gather of the operand (column+SP input, row+SP grad_output, same rule as
