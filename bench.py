@@ -624,6 +624,44 @@ def main():
                         "switching power, not kernel stalls"},
             "weight_quantize_ms_not_in_step": t_ct_w,
         }
+        if world == 1:
+            # The same step WITHOUT the transposed copies of X and W (fp8_transposes="grad_output"): X is cast row-wise
+            # only (3 instead of 4 B/element), dgrad and wgrad read the row-wise payloads of W and X K-major through
+            # ds_read_b64_tr_b8.  Same results bit for bit (tests/test_parity_r3_gpu.py); reported beside `value`, which
+            # stays on the reference's own data flow (transposes for all three tensors).
+            st2 = L.LinearFP8State(recipe, device=dev, fp8_transposes="grad_output")
+
+            def step2(first=False):
+                y2, saved2 = L.linear_forward(x, w, None, st2, is_first_microbatch=first)
+                L.linear_backward(dy, saved2, st2)
+                st2.update_fwd_bwd()
+
+            step2(first=True)
+            for _ in range(2):
+                step2()
+            torch.cuda.synchronize()
+            run2 = step2
+            if graph is not None:
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        step2()
+                    torch.cuda.current_stream().wait_stream(side)
+                    torch.cuda.synchronize()
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        step2()
+                    torch.cuda.synchronize()
+                    run2 = g2.replay
+                except Exception as exc:
+                    print(f"[bench] second graph unavailable ({type(exc).__name__}: {exc})", file=sys.stderr)
+                    torch.cuda.synchronize()
+            ms2 = time_kernel(run2, args.steps, warm=args.warmup)
+            result["extra"]["step_rowwise_x_and_w"] = {
+                "ms_per_step": ms2, "tflops": flops_per_step / (ms2 * 1e-3) / 1e12,
+                "what": "fp8_transposes='grad_output': no X^T / W^T, dgrad + wgrad read row-wise payloads K-major "
+                        "(ds_read_b64_tr_b8); bit-equal outputs"}
         if not args.no_grouped and world == 1:
             result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
             result["extra"]["c3_mxfp8_linear"] = mxfp8_c3(dev, max(5, args.steps // 4))

@@ -314,3 +314,68 @@ def test_grouped_linear_recipes_grouped_path_list_path_and_per_expert_linear(rec
             assert torch.equal(st_g.bwd_state.amax_history, st_l.bwd_state.amax_history)
     if recipe_name == "delayed":
         assert (st_g.fwd_state.scale[[0, 2]] != 1.0).all(), "delayed scales never moved"
+
+
+# ------------------------------------------------------------------------------------------ per-tensor FP8, K-major operands
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1024, 768, 384), (2304, 1152, 640), (272, 400, 96)])
+@pytest.mark.parametrize("fa,fb", [(E4, E4), (E4, E5)])
+def test_fp8_gemm_reads_rowwise_payloads_k_major_exact(M, N, K, fa, fb):
+    """A per-tensor FP8 tensor WITHOUT a transposed copy is read K-major (ds_read_b64_tr_b8): NN with W row-wise only
+    (operand A K-major), NT with X row-wise only (A K-major, B from its transpose), NT with neither transpose (both
+    K-major) and with only X's transpose (B K-major).  Small integers: exact, and equal to the all-transposes call.
+    Ref contract: transformer_engine.cpp:1131-1144 / cublaslt_gemm.cu non-TN canonicalisation."""
+    from transformer_engine_amd import general_gemm
+    from transformer_engine_amd.tensor import Float8Tensor
+    rng = np.random.default_rng(M + N + K)
+
+    def t(shape, fp8, scale_inv, with_t):
+        v = rng.integers(-3, 4, size=shape).astype(np.float32)
+        codes = oracle.float_to_fp8(v, FMT[fp8])
+        return Float8Tensor(shape=shape, dtype=torch.float32, data=torch.from_numpy(codes).cuda(),
+                            fp8_scale_inv=torch.full((1,), scale_inv, device="cuda"), fp8_dtype=fp8,
+                            data_transpose=torch.from_numpy(np.ascontiguousarray(codes.T)).cuda() if with_t else None), v
+
+    (W, w), (X, x), (dY, dy) = t((N, K), fa, 0.5, False), t((M, K), fa, 2.0, False), t((M, N), fb, 0.25, False)
+    (Wt, _), (Xt, _), (dYt, _) = [(Float8Tensor(shape=a.shape, dtype=torch.float32, data=a._data, fp8_scale_inv=a._scale_inv,
+                                                fp8_dtype=a._fp8_dtype, data_transpose=a._data.t().contiguous()), None)
+                                  for a in (W, X, dY)]
+    ref_dx = torch.from_numpy(dy).cuda().double() @ torch.from_numpy(w).cuda().double() * (0.25 * 0.5)
+    ref_dw = torch.from_numpy(dy).cuda().double().T @ torch.from_numpy(x).cuda().double() * (0.25 * 2.0)
+    dx, *_ = general_gemm(W, dY, out_dtype=torch.float32, layout="NN", grad=True)            # A K-major
+    dw_a, *_ = general_gemm(X, dYt, out_dtype=torch.float32, layout="NT", grad=True)         # A K-major, B transposed copy
+    dw_ab, *_ = general_gemm(X, dY, out_dtype=torch.float32, layout="NT", grad=True)         # both K-major
+    dw_b, *_ = general_gemm(Xt, dY, out_dtype=torch.float32, layout="NT", grad=True)         # B K-major only
+    dx_t, *_ = general_gemm(Wt, dYt, out_dtype=torch.float32, layout="NN", grad=True)        # all transposes (reference path)
+    dw_t, *_ = general_gemm(Xt, dYt, out_dtype=torch.float32, layout="NT", grad=True)
+    torch.cuda.synchronize()
+    assert torch.equal(dx.double(), ref_dx) and torch.equal(dx, dx_t)
+    for name, got in (("A", dw_a), ("AB", dw_ab), ("B", dw_b)):
+        assert torch.equal(got.double(), ref_dw), name
+        assert torch.equal(got, dw_t), name
+
+
+def test_linear_without_input_and_weight_transposes_equals_default():
+    """LinearFP8State(fp8_transposes="grad_output"): X and W are cast row-wise only (3 B/element, no X^T / W^T in memory),
+    dgrad / wgrad read them K-major; outputs and recipe state bit-equal to the default path over 3 steps."""
+    from transformer_engine_amd import linear as L
+    from transformer_engine_amd.recipe import DelayedScaling
+    M, K, N = 768, 512, 1024
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    sa = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"))
+    sb = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"), fp8_transposes="grad_output")
+    for it in range(3):
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+        dy = (torch.randn(M, N, generator=g) * 0.01).to(torch.bfloat16).cuda()
+        outs = []
+        for st in (sa, sb):
+            y, saved = L.linear_forward(x, w, None, st, is_first_microbatch=True)
+            dx, dw, _ = L.linear_backward(dy, saved, st)
+            st.update_fwd_bwd()
+            outs.append((y, dx, dw, saved))
+        torch.cuda.synchronize()
+        assert outs[1][3][0]._transpose is None and outs[1][3][1]._transpose is None     # no X^T, no W^T
+        assert outs[0][3][0]._transpose is not None
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(a, b), it
+        assert torch.equal(sa.fwd_state.scale, sb.fwd_state.scale) and torch.equal(sa.bwd_state.scale, sb.bwd_state.scale)

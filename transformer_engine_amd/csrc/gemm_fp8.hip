@@ -225,7 +225,8 @@ template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool M
           int KM = 0>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   static_assert(!(GROUPED && EPI), "the grouped variant has no extended epilogues");
-  static_assert(KM == 0 || (MX && !GROUPED && !EPI), "K-major operands: plain MXFP8 kernel only");
+  static_assert(KM == 0 || (!GROUPED && !EPI), "K-major operands: the plain (un-grouped, basic epilogue) kernels only");
+  static_assert(MX || (KM & 12) == 0, "scale-layout bits belong to the MXFP8 variants");
   // bits 2 / 3: that K-major operand's e8m0 scales are COMPACT, i.e. stored [k block][row] like the payload (the
   // reference's columnwise scale matrix); otherwise GEMM-swizzled, one format whatever the quantization direction.
   // Compile-time on purpose: a run-time branch in the main loop lets the scheduler tear up the pinned MFMA order
@@ -1159,30 +1160,37 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
   if (is_tensor_scaling(A.scaling_mode)) {
     // Per-tensor scaling.  nvte_is_non_tn_fp8_gemm_supported() == 0, so a non-transposed A
     // (transposed B) is replaced by its pre-transposed "columnwise" copy: every FP8 GEMM is TN.
-    if (transa) {
-      opA.data = static_cast<const uint8_t *>(A.data.ptr);
-      opA.dtype = A.data.dtype;
-      opA.scale_inv = A.scale_inv.ptr;
-      NVTE_CHECK(A.has_data(), "Input A is missing row-wise usage");
-    } else {
-      NVTE_CHECK(A.has_columnwise_data() && is_fp8(A.columnwise_data.dtype),
-                 "Input A is missing column-wise usage");
-      opA.data = static_cast<const uint8_t *>(A.columnwise_data.ptr);
-      opA.dtype = A.columnwise_data.dtype;
-      opA.scale_inv = A.columnwise_scale_inv.ptr;
-    }
-    if (!transb) {
-      opB.data = static_cast<const uint8_t *>(B.data.ptr);
-      opB.dtype = B.data.dtype;
-      opB.scale_inv = B.scale_inv.ptr;
-      NVTE_CHECK(B.has_data(), "Input B is missing row-wise usage");
-    } else {
-      NVTE_CHECK(B.has_columnwise_data() && is_fp8(B.columnwise_data.dtype),
-                 "Input B is missing column-wise usage");
-      opB.data = static_cast<const uint8_t *>(B.columnwise_data.ptr);
-      opB.dtype = B.columnwise_data.dtype;
-      opB.scale_inv = B.columnwise_scale_inv.ptr;
-    }
+    // An operand whose contraction runs over its stored rows is read from its pre-transposed copy when the tensor
+    // carries one; a tensor that only holds the ROW-WISE payload is read K-major through the transposing LDS loads
+    // instead (no transposed copy has to exist: 3 instead of 4 bytes per element on the quantize side, half the FP8
+    // memory of that tensor).  The reference takes that route where its GEMM reads non-TN FP8 operands
+    // (ref transformer_engine.cpp:1131-1144, pytorch/csrc/quantizer.cpp:342-356).
+    auto rowwise_of = [](const Tensor &T, Operand &op, const char *name) {
+      NVTE_CHECK(T.has_data(), "Input ", name, " is missing row-wise usage");
+      op.data = static_cast<const uint8_t *>(T.data.ptr);
+      op.dtype = T.data.dtype;
+      op.scale_inv = T.scale_inv.ptr;
+    };
+    auto contracted_over_rows = [&](const Tensor &T, Operand &op, const char *name, size_t rows) {
+      if (T.has_columnwise_data() && is_fp8(T.columnwise_data.dtype)) {
+        op.data = static_cast<const uint8_t *>(T.columnwise_data.ptr);
+        op.dtype = T.columnwise_data.dtype;
+        op.scale_inv = T.columnwise_scale_inv.ptr;
+        return;
+      }
+      NVTE_CHECK(T.has_data() && is_fp8(T.data.dtype), "Input ", name, " is missing column-wise usage (and holds no "
+                 "row-wise FP8 payload that could be read K-major)");
+      NVTE_CHECK(rows % 16 == 0, "FP8 GEMM: reading the row-wise payload of ", name, " K-major needs its last dimension (",
+                 rows, ") to be a multiple of 16; provide the transposed copy instead");
+      rowwise_of(T, op, name);
+      op.k_major = true;
+      op.ld = rows;
+    };
+    if (transa) rowwise_of(A, opA, "A"); else contracted_over_rows(A, opA, "A", m);
+    if (!transb) rowwise_of(B, opB, "B"); else contracted_over_rows(B, opB, "B", n);
+    if (opA.k_major || opB.k_major)
+      NVTE_CHECK(static_cast<unsigned long long>(k) * std::max(opA.ld, opB.ld) < (1ull << 32),
+                 "FP8 GEMM: K-major operand too large for 32-bit offsets");
     NVTE_CHECK(is_fp8(opA.dtype) && is_fp8(opB.dtype),
                "This library implements the FP8 GEMM only; got A dtype ", dtype_name(opA.dtype),
                ", B dtype ", dtype_name(opB.dtype));
@@ -1341,9 +1349,17 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
       case 11: launch_by_format<true, false, false, 11>(fp, fq, g, stream); break;
       default: launch_by_format<true, false, false, 15>(fp, fq, g, stream); break;
     }
-  } else if (mx)
+  } else if (mx) {
     ext ? launch_by_format<true, true>(fp, fq, g, stream) : launch_by_format<true, false>(fp, fq, g, stream);
-  else
+  } else if (opA.k_major || opB.k_major) {
+    NVTE_CHECK(!ext, "FP8 GEMM: the GELU / FP8-output epilogues read K-contiguous operands only; provide the transposed "
+               "copies (column-wise usage) for this call");
+    switch ((opB.k_major ? 1 : 0) | (opA.k_major ? 2 : 0)) {
+      case 1: launch_by_format<false, false, false, 1>(fp, fq, g, stream); break;
+      case 2: launch_by_format<false, false, false, 2>(fp, fq, g, stream); break;
+      default: launch_by_format<false, false, false, 3>(fp, fq, g, stream); break;
+    }
+  } else
     ext ? launch_by_format<false, true>(fp, fq, g, stream) : launch_by_format<false, false>(fp, fq, g, stream);
 
   if (dgelu_bgrad && bias->data.dtype != kNVTEFloat32) {
@@ -1352,8 +1368,8 @@ void gemm_impl(const Tensor &A, const Tensor &B, Tensor &D, const Tensor *bias, 
     NVTE_CHECK_HIP(hipGetLastError());
   }
   if (bgradb) {
-    NVTE_CHECK(!opB.k_major, "MXFP8 GEMM: the bias-gradient side kernel sums a K-contiguous operand B; quantize B with "
-               "the transposed columnwise layout (nvte_amd_set_columnwise_transposed) or compute dbias in the quantize "
+    NVTE_CHECK(!opB.k_major, "FP8 GEMM: the bias-gradient side kernel sums a K-contiguous operand B; give B its "
+               "transposed copy (MXFP8: nvte_amd_set_columnwise_transposed) or compute dbias in the quantize "
                "(nvte_quantize_dbias)");
     // operand B as the kernel reads it: [n, k] K-contiguous
     const dim3 grid(static_cast<unsigned>(ceil_div(n, 4))), block(256);

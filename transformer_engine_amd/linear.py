@@ -72,13 +72,21 @@ MX_COLUMNWISE_DEFAULT = "transposed"
 class LinearFP8State:
     """Per-module quantization state: recipe states + quantizers for one Linear."""
 
-    def __init__(self, recipe, device=None, compact_mx_scales=(), mx_columnwise: Optional[str] = None):
+    def __init__(self, recipe, device=None, compact_mx_scales=(), mx_columnwise: Optional[str] = None,
+                 fp8_transposes: str = "all"):
         """compact_mx_scales: which of "input", "weight", "grad_output" keep their MXFP8 scales in the compact
         layout (the others are written GEMM-swizzled, see below).
         mx_columnwise: layout of the MXFP8 columnwise copies that dgrad / wgrad read - "reference" (the payload keeps
         the tensor's own shape, what TE's MXFP8Tensor holds; the GEMM reads it K-major), "transposed" (the
         amd_ext.h extension, K-contiguous) or "mixed" (reference for input and weight, transposed for grad_output);
         default: NVTE_AMD_MX_COLUMNWISE, else MX_COLUMNWISE_DEFAULT."""
+        # per-tensor FP8: which tensors keep a transposed copy for the backward GEMMs.  "all" = the reference's
+        # behaviour where non-TN FP8 GEMMs are unsupported (input, weight, grad_output).  "grad_output": only dY - dgrad
+        # and wgrad then read the ROW-WISE payloads of W and X K-major (one K-major operand per GEMM, the rate of the
+        # K-contiguous kernel), X is cast at 3 instead of 4 bytes per element and neither X^T nor W^T is ever stored.
+        if fp8_transposes not in ("all", "grad_output"):
+            raise ValueError("fp8_transposes must be 'all' or 'grad_output'")
+        self.fp8_transposes = fp8_transposes
         self.recipe = recipe
         self.device = device or torch.device("cuda")
         self.fwd_state: Optional[DelayedScalingRecipeState] = None
@@ -143,12 +151,14 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
                    needs_backward: bool = True, out_dtype: Optional[torch.dtype] = None):
     """Returns (y, saved) where saved = (x8, w8) for the backward pass."""
     qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
-    qi.set_usage(rowwise=True, columnwise=needs_backward)          # linear.py:399-406
+    # per-tensor FP8 with fp8_transposes="grad_output": no transposed copies of X and W (read K-major in backward)
+    col = needs_backward and not (st.fp8_transposes == "grad_output" and not isinstance(qi, MXFP8Quantizer))
+    qi.set_usage(rowwise=True, columnwise=col)                     # linear.py:399-406
     x2d = x.reshape(-1, x.shape[-1])
     x8 = qi(x2d)                                                   # linear.py:407
     # weight: quantize on the first microbatch (or always when no caching was requested)
     if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
-        qw.set_usage(rowwise=True, columnwise=needs_backward)
+        qw.set_usage(rowwise=True, columnwise=col)
         w8 = qw(weight)                                            # linear.py:451-461
         if is_first_microbatch is not None:
             st.weight_cache = w8
