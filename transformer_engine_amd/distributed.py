@@ -328,6 +328,33 @@ def _mx_row_slice(w8: MXFP8Tensor, r0: int, r1: int) -> MXFP8Tensor:
                        with_gemm_swizzled_scales=w8._with_gemm_swizzled_scales)
 
 
+def _dgrad_operand_rows(w8):
+    """For dgrad = dY W cut along its output columns: a function (c0, c1) -> the weight restricted to input features
+    [c0, c1), built from ROW blocks of the K-contiguous copy the NN GEMM reads (per-tensor FP8: the transpose [K, N];
+    MXFP8: the transposed columnwise pair) - views only.  None when the weight carries no such copy."""
+    if isinstance(w8, Float8Tensor):
+        if w8._transpose is None or w8._transpose_invalid:
+            return None
+        N = w8.shape[0]
+        return lambda c0, c1: Float8Tensor(shape=(N, c1 - c0), dtype=w8.dtype, data=None, fp8_scale_inv=w8._scale_inv,
+                                           fp8_dtype=w8._fp8_dtype, data_transpose=w8._transpose[c0:c1])
+    if isinstance(w8, MXFP8Tensor) and w8._columnwise_transposed and w8._columnwise_data is not None:
+        K = w8.shape[-1]
+        N = w8.numel() // K
+        sc = w8._columnwise_scale_inv
+        stride = sc.numel() // ((K + 127) // 128 * 128)
+
+        def rows(c0, c1):
+            assert c0 % 128 == 0 and (c1 % 128 == 0 or c1 == K)
+            return MXFP8Tensor(shape=(N, c1 - c0), dtype=w8.dtype, rowwise_data=None, rowwise_scale_inv=None,
+                               columnwise_data=w8._columnwise_data.view(K, N)[c0:c1],
+                               columnwise_scale_inv=sc.view(-1, stride)[c0:(c1 + 127) // 128 * 128],
+                               fp8_dtype=w8._fp8_dtype, with_gemm_swizzled_scales=w8._with_gemm_swizzled_scales,
+                               columnwise_transposed=True)
+        return rows
+    return None
+
+
 def gather_along_first_dim(inp, group=None, quantizer=None, need_transpose: bool = False):
     """ref pytorch/distributed.py:1665: quantize locally (rowwise only for per-tensor FP8: a gathered
     transpose is not the transpose of the gather, linear.py:361-363), then all-gather bytes."""
@@ -495,9 +522,20 @@ class ColumnParallelLinearSP:
         qg = st.bwd_q[BWD_GRAD_OUTPUT]
         qg.set_usage(rowwise=True, columnwise=True)
         dy8 = qg(dy)
-        # dgrad partial sums [M_total, K] -> reduce-scatter to this rank's tokens, asynchronously
-        dx_partial, *_ = general_gemm(w8, dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
-        dx_local, handle = reduce_scatter_along_first_dim(dx_partial, self.group, async_op=True)
+        # dgrad partial sums [M_total, K] -> reduce-scatter to this rank's tokens, asynchronously.  With the overlap on,
+        # dgrad is cut along its OUTPUT columns (row blocks of the K-contiguous W^T copy: views, no copy): piece j's
+        # reduce-scatter starts under dgrad piece j+1 instead of only under wgrad - at tp = 8 the whole reduce-scatter
+        # (bf16, 8192 tp x K x 2 B x (tp-1)/tp) is longer than the wgrad GEMM it used to hide under (section 4).
+        handle = None
+        w8t = _dgrad_operand_rows(w8) if (self.overlap and collectives_active(self.group)) else None
+        if w8t is not None:
+            def cols_gemm(c0, c1):
+                out, *_ = general_gemm(w8t(c0, c1), dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
+                return out
+            dx_local = gemm_and_reduce_scatter_nchunked(self.K, cols_gemm, self.group, self.chunks)
+        else:
+            dx_partial, *_ = general_gemm(w8, dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
+            dx_local, handle = reduce_scatter_along_first_dim(dx_partial, self.group, async_op=True)
         # wgrad needs X^T of the GATHERED input: rebuilt locally (ref distributed.py:1067-1075)
         if isinstance(x8, _GatheredChunks):
             x8 = x8.as_transposed_tensor()
