@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--gemm-cus", type=int, default=0,
                     help="cap the persistent GEMM grid at this many CUs (NVTE_EXT_MARGIN_SM of the reference: the rest is "
                          "left to the RCCL kernels of an overlapped step); 0 = all")
+    ap.add_argument("--rehearse-multi", action="store_true",
+                    help="N = 1 only: take the N > 1 code paths (two graphs + side-stream amax all-reduce for dp, the sharded "
+                         "layers for tp_sp) over a world-size-1 RCCL group with the collectives forced on - what a one-GPU box "
+                         "can execute of the multi-GPU run; the numbers it prints are not a scaling result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grouped", action="store_true", help="skip the configs[4]-shaped GroupedLinear side measurement")
     return ap.parse_args()
@@ -207,12 +211,21 @@ def main():
     from transformer_engine_amd.recipe import DelayedScaling
 
     dist = None
-    if world > 1:
+    multi = world > 1 or args.rehearse_multi      # which code paths run (world stays the number of ranks)
+    if multi:
         import torch.distributed as dist
+        if world == 1:
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if world == 1:
+            from transformer_engine_amd import distributed as _D
+            _D.force_collectives(True)
 
     M, K, N = args.tokens, args.in_features, args.out_features
     torch.manual_seed(1234 + rank)
@@ -254,7 +267,7 @@ def main():
         parallelism = f"ep{world} ({G} experts per rank)"
         global_tokens = sum(all_splits)
         ep_info = {"experts": E, "experts_per_rank": G, "m_splits_all": all_splits}
-    elif world == 1 or args.parallelism == "dp":
+    elif (not multi) or args.parallelism == "dp":
         x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
         dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
@@ -269,7 +282,7 @@ def main():
             return y, dx, dw
 
         flops_per_step = 6.0 * M * N * K * world     # whole job
-        parallelism = "single" if world == 1 else f"dp{world}"
+        parallelism = "single" if not multi else f"dp{world}"
         global_tokens = M * world
     else:
         from transformer_engine_amd import distributed as D
@@ -304,10 +317,10 @@ def main():
     torch.cuda.synchronize()
 
     # RCCL collectives are left out of graph capture; the expert-parallel step has none (per-rank graph)
-    use_graph = (not args.no_graph) and (world == 1 or args.parallelism == "ep")
+    use_graph = (not args.no_graph) and ((not multi) or args.parallelism == "ep")
     graph = None
     seg = None
-    if (not args.no_graph) and world > 1 and args.parallelism == "dp":
+    if (not args.no_graph) and multi and args.parallelism == "dp":
         # N data-parallel replicas: the same kernels as at N = 1, replayed from TWO graphs (forward,
         # backward) with the recipe's packed amax all_reduce(MAX) + scale update issued eagerly between
         # them - no collective is ever captured.
@@ -361,8 +374,8 @@ def main():
     # scales are only read by the NEXT step's forward graph, the backward scales by the next backward graph,
     # and no kernel of the other graph touches that recipe state - same values as the serial order, two
     # collective latencies per step off the critical path.
-    comm = torch.cuda.Stream() if world > 1 else None
-    ev = {k: torch.cuda.Event() for k in ("f", "fd", "b", "bd")} if world > 1 else None
+    comm = torch.cuda.Stream() if multi else None
+    ev = {k: torch.cuda.Event() for k in ("f", "fd", "b", "bd")} if multi else None
 
     def run_segments():
         main = torch.cuda.current_stream()
@@ -417,6 +430,8 @@ def main():
                       if seg is not None else {})},
         "tflops_per_gpu": tflops / world,
     }
+    if args.rehearse_multi and world == 1:
+        result["rehearsal"] = "N > 1 code paths over a world-size-1 RCCL group with forced collectives: not a scaling result"
     if ep_info is not None:
         result["scaling"] = "strong"
         result["dtype"] = "fp8(e4m3/e5m2)->f32acc"
@@ -430,7 +445,7 @@ def main():
     if args.gemm_cus > 0:
         result["config"]["gemm_cus"] = args.gemm_cus
 
-    if world > 1 and args.parallelism == "tp_sp":
+    if multi and args.parallelism == "tp_sp":
         # ---- exposed communication: the same step (a) with the pipelines switched off (one blocking
         # collective, then the whole GEMM) and (b) the step's collectives alone, same sizes, back to back.
         # comm_ms = (b); overlap_frac = the share of (b) the overlapped schedule hides = ((a) - step) / (b).
@@ -474,7 +489,7 @@ def main():
                                          "reduce_scatter_bf16": rs_src.numel() * 2 * (world - 1) // world}
         result["config"]["tp_chunks"] = args.tp_chunks
 
-    if (world == 1 or args.parallelism == "dp") and args.parallelism != "ep":
+    if ((not multi) or args.parallelism == "dp") and args.parallelism != "ep":
         # ---- per-kernel measurements (HIP events on the launch stream) -------------------------
         # every rank runs them (the instrumented steps contain the recipe's amax all-reduce); rank 0 reports
         from transformer_engine_amd import general_gemm
@@ -624,7 +639,7 @@ def main():
                         "switching power, not kernel stalls"},
             "weight_quantize_ms_not_in_step": t_ct_w,
         }
-        if world == 1:
+        if not multi:
             # The same step WITHOUT the transposed copies of X and W (fp8_transposes="grad_output"): X is cast row-wise
             # only (3 instead of 4 B/element), dgrad and wgrad read the row-wise payloads of W and X K-major through
             # ds_read_b64_tr_b8.  Same results bit for bit (tests/test_parity_r3_gpu.py); reported beside `value`, which
@@ -662,10 +677,10 @@ def main():
                 "ms_per_step": ms2, "tflops": flops_per_step / (ms2 * 1e-3) / 1e12,
                 "what": "fp8_transposes='grad_output': no X^T / W^T, dgrad + wgrad read row-wise payloads K-major "
                         "(ds_read_b64_tr_b8); bit-equal outputs"}
-        if not args.no_grouped and world == 1:
+        if not args.no_grouped and not multi:
             result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
             result["extra"]["c3_mxfp8_linear"] = mxfp8_c3(dev, max(5, args.steps // 4))
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not multi:
             result["cpu_baseline"] = cpu_baseline()
             # configs[0] (the reference's CPU-runnable case: Linear 768 -> 3072, 2048 tokens) in full, CPU and GPU
             c1 = cpu_baseline(tokens=2048, K=768, N=3072)
