@@ -22,7 +22,10 @@ qm = MXFP8Quantizer(DType.kFloat8E4M3); qm.optimize_for_gemm = True
 a8 = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16, generator=g); b8 = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16, generator=g)
 am, bm = qm(a8), qm(b8)
 o8 = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
-fns = {"fprop": lambda: general_gemm(wq, xq, layout="TN", out=y), "dgrad": lambda: general_gemm(wq, dyq, layout="NN", out=dx),
+xs = q8(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g)); wsm = q8(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g))
+qms = MXFP8Quantizer(DType.kFloat8E4M3); qms.optimize_for_gemm = True
+xsm, wsmm = qms(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g)), qms(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g))
+fns = {"k256": lambda: general_gemm(wsm, xs, layout="TN", out=o8), "mxk256": lambda: general_gemm(wsmm, xsm, layout="TN", out=o8), "fprop": lambda: general_gemm(wq, xq, layout="TN", out=y), "dgrad": lambda: general_gemm(wq, dyq, layout="NN", out=dx),
        "wgrad": lambda: general_gemm(xq, dyq, layout="NT", out=dw), "mx8192": lambda: general_gemm(am, bm, layout="TN", out=o8)}
 t0 = time.time()
 while time.time() - t0 < 1.0:
@@ -43,7 +46,8 @@ rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
 acc = {l: {} for l in libs}
 for r in range(rounds):
     for l in libs:
-        env = dict(os.environ, TE_AMD_LIBRARY=os.path.abspath(l))
+        lib, *kv = l.split("@")
+        env = dict(os.environ, TE_AMD_LIBRARY=os.path.abspath(lib), **dict(x.split("=") for x in kv))
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
         line = [x for x in out.stdout.splitlines() if x.startswith("RES")]
         if not line:
