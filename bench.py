@@ -35,7 +35,7 @@ PEAK_FP8_TFLOPS = 5000.0   # dense FP8 MFMA, MI355X_MICROARCH.md "Peak FP8 MFMA 
 PEAK_HBM_GBPS = 8000.0     # HBM3E spec, MI355X_MICROARCH.md
 # newest first: the PMC passes (profiles/collect.sh) of the kernels this tree ships; each file records the
 # commit and date it was taken at under "_meta"
-TRAFFIC_FILES = ("round2_traffic.json", "round1_traffic.json")
+TRAFFIC_FILES = ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json")
 
 
 def parse():
@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--gemm-cus", type=int, default=0,
                     help="cap the persistent GEMM grid at this many CUs (NVTE_EXT_MARGIN_SM of the reference: the rest is "
                          "left to the RCCL kernels of an overlapped step); 0 = all")
+    ap.add_argument("--fp8-transposes", default="none", choices=["none", "grad_output", "all"],
+                    help="which per-tensor FP8 tensors keep a transposed copy for the backward GEMMs (LinearFP8State): 'none' = "
+                         "the library default (row-wise payloads read K-major by dgrad / wgrad), 'all' = the data flow of "
+                         "rounds 1-2 (cast_transpose for X and dY); outputs are bit-equal")
     ap.add_argument("--rehearse-multi", action="store_true",
                     help="N = 1 only: take the N > 1 code paths (two graphs + side-stream amax all-reduce for dp, the sharded "
                          "layers for tp_sp) over a world-size-1 RCCL group with the collectives forced on - what a one-GPU box "
@@ -271,7 +275,7 @@ def main():
         x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
         w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
         dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
-        st = L.LinearFP8State(recipe, device=dev)
+        st = L.LinearFP8State(recipe, device=dev, fp8_transposes=args.fp8_transposes)
 
         def step(first=False):
             # the recipe step of BOTH directions is one launch behind the backward pass (LinearFP8State.update_fwd_bwd:
@@ -426,6 +430,7 @@ def main():
                                "(HYBRID), fwd+bwd, 8192 tokens per GPU",
                    "tokens": global_tokens, "in_features": K, "out_features": N, "parallelism": parallelism,
                    "hip_graph": graph is not None or seg is not None, "weight_quantize": "amortised (is_first_microbatch=False)",
+                   **({"fp8_transposes": args.fp8_transposes} if ((not multi) or args.parallelism == "dp") else {}),
                    **({"amax_reduction": "all_reduce(MAX) + scale update on a side stream, behind the other graph"}
                       if seg is not None else {})},
         "tflops_per_gpu": tflops / world,
@@ -495,16 +500,34 @@ def main():
         from transformer_engine_amd import general_gemm
         it = max(10, args.steps // 2)
         qi, qw, qg = st.fwd_q[L.FWD_INPUT], st.fwd_q[L.FWD_WEIGHT], st.bwd_q[L.BWD_GRAD_OUTPUT]
+        mode = args.fp8_transposes
+        # which tensors carry a transposed copy in the timed step (LinearFP8State.fp8_transposes)
+        cols = {"all": (True, True, True), "grad_output": (False, False, True), "none": (False, False, False)}
+
+        def operands(flags):
+            """FP8 X, W, dY (+ preallocated outputs of the same kind) with / without transposed copies."""
+            outs, empties = [], []
+            for q, t, c in zip((qi, qw, qg), (x, w, dy), flags):
+                q.set_usage(rowwise=True, columnwise=c)
+                outs.append(q(t))
+                empties.append(q.make_empty(t.shape, dtype=t.dtype, device=dev))
+            return outs, empties
+
+        # cast + transpose in isolation (the metric's second half), always measured
+        (x8t, w8t, dy8t), (oxt, owt, odyt) = operands(cols["all"])
         for q in (qi, qw, qg):
             q.set_usage(rowwise=True, columnwise=True)
-        x8, w8, dy8 = qi(x), qw(w), qg(dy)
-        ox, ow, ody = (q.make_empty(t.shape, dtype=t.dtype, device=dev) for q, t in ((qi, x), (qw, w), (qg, dy)))
-        t_ct_x = time_kernel(lambda: qi.update_quantized(x, ox), it)
-        t_ct_w = time_kernel(lambda: qw.update_quantized(w, ow), it)
-        t_ct_dy = time_kernel(lambda: qg.update_quantized(dy, ody), it)
+        t_ct_x = time_kernel(lambda: qi.update_quantized(x, oxt), it)
+        t_ct_w = time_kernel(lambda: qw.update_quantized(w, owt), it)
+        t_ct_dy = time_kernel(lambda: qg.update_quantized(dy, odyt), it)
         y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
         dw = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
+        # the GEMMs in isolation, on the operands of the timed step (K-major reads where it keeps no transposes)
+        if mode == "all":
+            x8, w8, dy8 = x8t, w8t, dy8t
+        else:
+            (x8, w8, dy8), _ = operands(cols[mode])
         t_fprop = time_kernel(lambda: general_gemm(w8, x8, layout="TN", out=y), it)
         t_dgrad = time_kernel(lambda: general_gemm(w8, dy8, layout="NN", out=dx, grad=True), it)
         t_wgrad = time_kernel(lambda: general_gemm(x8, dy8, layout="NT", out=dw, grad=True), it)
@@ -523,71 +546,92 @@ def main():
         # roofline uses - they include the cache state a real step leaves behind (a kernel launched
         # back to back on the same operands finds part of them in the 256 MiB Infinity Cache) and they
         # are what `rocprofv3 --kernel-trace --stats -- python3 bench.py` averages (profiles/).
-        in_step = {k: [] for k in ("cast_transpose_x", "gemm_fprop", "cast_transpose_dy", "gemm_dgrad", "gemm_wgrad",
-                                   "empty_pair")}
+        roles = ("quantize_x", "gemm_fprop", "quantize_dy", "gemm_dgrad", "gemm_wgrad", "empty_pair")
 
-        class rec:
-            def __init__(self, role):
-                self.role = role
-                self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        def instrument(flags, state):
+            """args.steps eager steps with event pairs; flags = which of X / W / dY carry a transposed copy."""
+            in_step = {k: [] for k in roles}
+            (_, wq8, _), (ox, _, ody) = operands(flags)
 
-            def __enter__(self):
-                self.a.record()
+            class rec:
+                def __init__(self, role):
+                    self.role = role
+                    self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-            def __exit__(self, *exc):
-                self.b.record()
-                in_step[self.role].append((self.a, self.b))
+                def __enter__(self):
+                    self.a.record()
 
-        def instrumented_step():
-            qi.set_usage(rowwise=True, columnwise=True)
-            with rec("cast_transpose_x"):
-                qi.update_quantized(x, ox)
-            sx8 = ox
-            # outputs preallocated (y / dx / dw above): an allocator call between the two events of a pair would be
-            # charged to the kernel (seen: one 67 MB torch.empty stalling a dgrad pair to 0.9 ms)
-            with rec("gemm_fprop"):
-                general_gemm(st.weight_cache, sx8, layout="TN", out=y)
-            qg.set_usage(rowwise=True, columnwise=True)
-            with rec("cast_transpose_dy"):
-                qg.update_quantized(dy, ody)
-            sdy8 = ody
-            with rec("gemm_dgrad"):
-                general_gemm(st.weight_cache, sdy8, layout="NN", grad=True, out=dx)
-            with rec("gemm_wgrad"):
-                general_gemm(sx8, sdy8, layout="NT", grad=True, out=dw)
-            with rec("empty_pair"):      # two records with nothing between them: what a pair adds to any kernel
-                pass
-            st.update_fwd_bwd()
+                def __exit__(self, *exc):
+                    self.b.record()
+                    in_step[self.role].append((self.a, self.b))
 
-        for _ in range(3):
-            instrumented_step()
-        for v in in_step.values():
-            v.clear()
-        for _ in range(args.steps):
-            instrumented_step()
-        torch.cuda.synchronize()
-        # mean per kernel; a pair more than 2x its median holds a host stall between the two records (seen under
-        # rocprofv3: one 8 ms pair around a 0.37 ms kernel whose traced duration was normal) and is dropped, counted below
-        samples = {k: sorted(a.elapsed_time(b) for a, b in v) for k, v in in_step.items()}
-        kept = {k: [t for t in s if t <= 2.0 * s[len(s) // 2]] for k, s in samples.items()}
-        step_ms = {k: sum(v) / len(v) for k, v in kept.items()}
+            def instrumented_step():
+                qi.set_usage(rowwise=True, columnwise=flags[0])
+                with rec("quantize_x"):
+                    qi.update_quantized(x, ox)
+                # outputs preallocated (y / dx / dw above): an allocator call between the two events of a pair would be
+                # charged to the kernel (seen: one 67 MB torch.empty stalling a dgrad pair to 0.9 ms)
+                with rec("gemm_fprop"):
+                    general_gemm(wq8, ox, layout="TN", out=y)
+                qg.set_usage(rowwise=True, columnwise=flags[2])
+                with rec("quantize_dy"):
+                    qg.update_quantized(dy, ody)
+                with rec("gemm_dgrad"):
+                    general_gemm(wq8, ody, layout="NN", grad=True, out=dx)
+                with rec("gemm_wgrad"):
+                    general_gemm(ox, ody, layout="NT", grad=True, out=dw)
+                with rec("empty_pair"):      # two records with nothing between them: what a pair adds to any kernel
+                    pass
+                state.update_fwd_bwd()
+
+            for _ in range(3):
+                instrumented_step()
+            for v in in_step.values():
+                v.clear()
+            for _ in range(args.steps):
+                instrumented_step()
+            torch.cuda.synchronize()
+            # mean per kernel; a pair more than 2x its median holds a host stall between the two records (seen under
+            # rocprofv3: one 8 ms pair around a 0.37 ms kernel whose traced duration was normal) and is dropped, counted below
+            smp = {k: sorted(a.elapsed_time(b) for a, b in v) for k, v in in_step.items()}
+            kpt = {k: [t for t in s_ if t <= 2.0 * s_[len(s_) // 2]] for k, s_ in smp.items()}
+            return smp, kpt, {k: sum(v) / len(v) for k, v in kpt.items()}
+
+        samples, kept, step_ms = instrument(cols[mode], st)
+        if mode == "all":
+            ct_step_ms = step_ms
+        else:   # the cast + transpose kernel inside a step: the same step with transposed copies for all three tensors
+            _, _, ct_step_ms = instrument(cols["all"], L.LinearFP8State(recipe, device=dev, fp8_transposes="all"))
         gemm_avg_ms = (step_ms["gemm_fprop"] + step_ms["gemm_dgrad"] + step_ms["gemm_wgrad"]) / 3.0
         achieved = gemm_flops / (gemm_avg_ms * 1e-3) / 1e12
         traffic = load_traffic()
         default_shape = (M, K, N) == (8192, 4096, 14336)   # the committed passes were taken on these shapes
-        g_traffic = [traffic_of(traffic, r) if default_shape else None for r in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")]
+        sfx = "" if mode == "all" else "_" + mode          # roles of profiles/pmc_target.py
+        g_traffic = [traffic_of(traffic, r + sfx) if default_shape else None for r in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")]
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP8_TFLOPS, "unit": "TFLOP/s",
                               "frac": achieved / PEAK_FP8_TFLOPS,
                               "traffic": (sum(g_traffic) / 3.0) if all(t is not None for t in g_traffic) else None,
                               "traffic_unit": "bytes/launch (fabric side: HBM + Infinity Cache; fprop/dgrad/wgrad mean)",
-                              "kernel": "gemm_fp8_kernel (fprop/dgrad/wgrad average, 2*M*N*K FLOP per launch)"}
+                              "kernel": "gemm_fp8_kernel (fprop/dgrad/wgrad average, 2*M*N*K FLOP per launch"
+                                        + ("" if mode == "all" else "; dgrad / wgrad read row-wise payloads K-major") + ")"}
         ct_bytes = dy.numel() * 4.0      # 2 B read + 1 B rowwise + 1 B transposed per bf16 element
-        ct_gbps = ct_bytes / (step_ms["cast_transpose_dy"] * 1e-3) / 1e9
+        ct_gbps = ct_bytes / (ct_step_ms["quantize_dy"] * 1e-3) / 1e9
         result["roofline_cast_transpose"] = {"bound": "hbm", "achieved": ct_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                              "frac": ct_gbps / PEAK_HBM_GBPS,
                                              "traffic": traffic_of(traffic, "cast_transpose_dy") if default_shape else None,
                                              "algorithmic_bytes": ct_bytes,
-                                             "kernel": "cast_transpose_tile_kernel on dY [8192,14336] bf16->e5m2, 4 B/element"}
+                                             "kernel": "cast_transpose_tile_kernel on dY [8192,14336] bf16->e5m2, 4 B/element"
+                                                       + ("" if mode == "all" else " (inside the fp8_transposes='all' step)")}
+        if mode != "all":
+            # what the timed step runs instead: the row-wise cast, 3 B/element
+            c_bytes = dy.numel() * 3.0
+            c_gbps = c_bytes / (step_ms["quantize_dy"] * 1e-3) / 1e9
+            result["roofline_cast"] = {"bound": "hbm", "achieved": c_gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                       "frac": c_gbps / PEAK_HBM_GBPS, "algorithmic_bytes": c_bytes,
+                                       "traffic": traffic_of(traffic, "cast_dy") if default_shape else None,
+                                       "launch_ms": step_ms["quantize_dy"],
+                                       "kernel": ("cast_flat_kernel" if mode == "none" else "cast_transpose_tile_kernel")
+                                                 + " on dY [8192,14336] bf16->e5m2 inside the timed step"}
         meta = traffic.get("_meta", {})
         result["roofline"]["traffic_source"] = {
             "file": traffic.get("_file"), "commit": meta.get("commit"), "date": meta.get("date"),
@@ -595,25 +639,25 @@ def main():
                    "shapes), not read live: counters cannot be collected from inside this process"}
         result["roofline"]["launch_ms"] = {k: step_ms[k] for k in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")}
         result["roofline"]["timing"] = "HIP events around each launch inside args.steps eager steps of the timed workload"
-        result["roofline"]["launch_ms_min_median_max"] = {k: [s[0], s[len(s) // 2], s[-1]] for k, s in samples.items()}
+        result["roofline"]["launch_ms_min_median_max"] = {k: [s_[0], s_[len(s_) // 2], s_[-1]] for k, s_ in samples.items()}
         result["roofline"]["stalled_pairs_dropped"] = {k: len(samples[k]) - len(kept[k]) for k in samples}
         result["roofline"]["event_pair_floor_ms"] = step_ms["empty_pair"]    # included in every launch_ms above, not subtracted
         # cross-check against the timed region itself: the medians of the instrumented launches add up to the
         # replayed step (see extra.step_breakdown), the means carry the eager loop's occasional +20 % launches
         med = [samples[k][len(samples[k]) // 2] for k in ("gemm_fprop", "gemm_dgrad", "gemm_wgrad")]
         result["roofline"]["frac_at_median_launch"] = gemm_flops / (sum(med) / 3.0 * 1e-3) / 1e12 / PEAK_FP8_TFLOPS
-        result["roofline_cast_transpose"]["launch_ms"] = step_ms["cast_transpose_dy"]
+        result["roofline_cast_transpose"]["launch_ms"] = ct_step_ms["quantize_dy"]
         # headline both ways: `value` amortises the weight quantize as te.Linear does with
         # is_first_microbatch=False; the other figure charges one full weight cast_transpose to every step
         result["value_incl_weight_quantize"] = flops_per_step / ((ms_per_step + t_ct_w) * 1e-3) / 1e12
-        hot_kernels = ("cast_transpose_x", "gemm_fprop", "cast_transpose_dy", "gemm_dgrad", "gemm_wgrad")
+        hot_kernels = ("quantize_x", "gemm_fprop", "quantize_dy", "gemm_dgrad", "gemm_wgrad")
         hot_ms = sum(step_ms[k] for k in hot_kernels)
         hot_net_ms = hot_ms - len(hot_kernels) * step_ms["empty_pair"]     # every event pair carries the floor of its own
         result["extra"] = {
             "step_breakdown": {
                 "ms_per_step": ms_per_step, "hot_kernels_ms": hot_ms, "hot_kernels_net_of_event_floor_ms": hot_net_ms,
                 "gemm_ms": step_ms["gemm_fprop"] + step_ms["gemm_dgrad"] + step_ms["gemm_wgrad"],
-                "cast_transpose_ms": step_ms["cast_transpose_x"] + step_ms["cast_transpose_dy"],
+                "quantize_ms": step_ms["quantize_x"] + step_ms["quantize_dy"],
                 "recipe_kernel_and_launch_gaps_ms": ms_per_step - hot_net_ms,
                 "recipe_kernel_and_launch_gaps_share": (ms_per_step - hot_net_ms) / ms_per_step,
                 "note": "hot kernels timed in eager instrumented steps (HIP event pairs, the measured empty-pair floor "
@@ -621,6 +665,7 @@ def main():
                         "recipe-update kernel of the step (forward + backward states in one launch; amax rows are "
                         "zeroed by that kernel, there is no memset) and the graph's five inter-kernel gaps"},
             "in_step_ms": step_ms,
+            "in_step_ms_with_all_transposes": ct_step_ms,
             "isolated_note": "gemm_ms / cast_transpose_ms below: the same kernel launched back to back on resident "
                              "operands (upper bound: inputs partly stay in the Infinity Cache)",
             "gemm_ms": {"fprop": t_fprop, "dgrad": t_dgrad, "wgrad": t_wgrad},
@@ -640,43 +685,53 @@ def main():
             "weight_quantize_ms_not_in_step": t_ct_w,
         }
         if not multi:
-            # The same step WITHOUT the transposed copies of X and W (fp8_transposes="grad_output"): X is cast row-wise
-            # only (3 instead of 4 B/element), dgrad and wgrad read the row-wise payloads of W and X K-major through
-            # ds_read_b64_tr_b8.  Same results bit for bit (tests/test_parity_r3_gpu.py); reported beside `value`, which
-            # stays on the reference's own data flow (transposes for all three tensors).
-            st2 = L.LinearFP8State(recipe, device=dev, fp8_transposes="grad_output")
+            # The same step with the other settings of LinearFP8State.fp8_transposes ("all": transposed copies of X, W
+            # and dY as in rounds 1-2; "grad_output": only dY^T; "none": no FP8 transpose, the GEMMs read row-wise
+            # payloads K-major through ds_read_b64_tr_b8).  Same results bit for bit (tests/test_parity_r3_gpu.py).
+            def variant_step(vmode):
+                st2 = L.LinearFP8State(recipe, device=dev, fp8_transposes=vmode)
 
-            def step2(first=False):
-                y2, saved2 = L.linear_forward(x, w, None, st2, is_first_microbatch=first)
-                L.linear_backward(dy, saved2, st2)
-                st2.update_fwd_bwd()
+                def step2(first=False):
+                    y2, saved2 = L.linear_forward(x, w, None, st2, is_first_microbatch=first)
+                    L.linear_backward(dy, saved2, st2)
+                    st2.update_fwd_bwd()
 
-            step2(first=True)
-            for _ in range(2):
-                step2()
-            torch.cuda.synchronize()
-            run2 = step2
-            if graph is not None:
-                try:
-                    side = torch.cuda.Stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        step2()
-                    torch.cuda.current_stream().wait_stream(side)
-                    torch.cuda.synchronize()
-                    g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2):
-                        step2()
-                    torch.cuda.synchronize()
-                    run2 = g2.replay
-                except Exception as exc:
-                    print(f"[bench] second graph unavailable ({type(exc).__name__}: {exc})", file=sys.stderr)
-                    torch.cuda.synchronize()
-            ms2 = time_kernel(run2, args.steps, warm=args.warmup)
-            result["extra"]["step_rowwise_x_and_w"] = {
-                "ms_per_step": ms2, "tflops": flops_per_step / (ms2 * 1e-3) / 1e12,
-                "what": "fp8_transposes='grad_output': no X^T / W^T, dgrad + wgrad read row-wise payloads K-major "
-                        "(ds_read_b64_tr_b8); bit-equal outputs"}
+                step2(first=True)
+                for _ in range(2):
+                    step2()
+                torch.cuda.synchronize()
+                run2 = step2
+                if graph is not None:
+                    try:
+                        side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            step2()
+                        torch.cuda.current_stream().wait_stream(side)
+                        torch.cuda.synchronize()
+                        g2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g2):
+                            step2()
+                        torch.cuda.synchronize()
+                        run2 = g2.replay
+                    except Exception as exc:
+                        print(f"[bench] second graph unavailable ({type(exc).__name__}: {exc})", file=sys.stderr)
+                        torch.cuda.synchronize()
+                return time_kernel(run2, args.steps, warm=args.warmup)
+
+            what = {"all": "fp8_transposes='all' (the data flow of rounds 1-2): cast_transpose for X and dY, every GEMM "
+                           "operand K-contiguous",
+                    "grad_output": "fp8_transposes='grad_output': no X^T / W^T, dgrad + wgrad read the row-wise payloads of "
+                                   "W and X K-major (ds_read_b64_tr_b8)",
+                    "none": "fp8_transposes='none': X, W and dY are cast row-wise only (3 B/element, no FP8 transpose in "
+                            "the layer), dgrad reads W and wgrad reads X and dY K-major"}
+            result["extra"]["step_variants"] = {"note": "the same step with the other settings of LinearFP8State."
+                                                        "fp8_transposes; outputs and recipe state are bit-equal "
+                                                        "(tests/test_parity_r3_gpu.py); `value` is the '%s' one" % mode}
+            for other in ("all", "grad_output", "none"):
+                ms_o = ms_per_step if other == mode else variant_step(other)
+                result["extra"]["step_variants"][other] = {"ms_per_step": ms_o, "tflops": flops_per_step / (ms_o * 1e-3) / 1e12,
+                                                           "what": what[other]}
         if not args.no_grouped and not multi:
             result["extra"]["c5_grouped_linear"] = grouped_c5(dev, max(5, args.steps // 4))
             result["extra"]["c3_mxfp8_linear"] = mxfp8_c3(dev, max(5, args.steps // 4))

@@ -4,10 +4,13 @@ for each hot kernel of the configs[1] step.
 Corrections per MI355X_MICROARCH.md 'HBM': both counters are in KiB; on gfx950 FETCH_SIZE tallies
 128-byte requests at 64 bytes, so it is doubled for the 16-byte-per-lane streaming reads these
 kernels issue; WRITE_SIZE is taken as is.
-Roles come from the dispatch order of pmc_target.py: three set-up cast_transposes (X, W, dY), then
-per repetition cast_transpose X, GEMM fprop, cast_transpose dY, GEMM dgrad, GEMM wgrad.
+Roles come from the dispatch order of pmc_target.py: three set-up cast_transposes (X, W, dY) and three set-up
+row-wise casts, then per repetition cast_transpose X, GEMM fprop, cast_transpose dY, GEMM dgrad, GEMM wgrad, and - second
+loop, the step without FP8 transposes - cast X, GEMM fprop, cast dY, GEMM dgrad (kernel variant KM = 2: W read K-major),
+GEMM wgrad (KM = 3: X and dY K-major), reported as cast_x / cast_dy / gemm_*_none.
 Usage: python3 profiles/parse_pmc.py <fetch_results.db> <write_results.db> <out.json>"""
 import json
+import re
 import sqlite3
 import sys
 
@@ -20,17 +23,28 @@ def collect(db, counter):
     cur = sqlite3.connect(db).cursor()
     q = ("select kernel_name, value from counters_collection where counter_name = ? "
          "and kernel_name like '%te::%' order by dispatch_id")
-    per, n_gemm, n_ct = {}, 0, 0
-    for name, value in cur.execute(q, (counter,)):
+    rows = list(cur.execute(q, (counter,)))
+    km_of = lambda name: int(re.search(r"gemm_fp8_kernel<([^>]*)>", name).group(1).split(",")[-1])
+    reps = sum(1 for name, _ in rows if "gemm_fp8_kernel" in name and km_of(name) == 2)   # one K-major dgrad per repetition
+    per, n_gemm0, n_ct, n_flat = {}, 0, 0, 0
+    for name, value in rows:
         if "gemm_fp8_kernel" in name:
-            role = GEMM_ROLES[n_gemm % 3]
-            n_gemm += 1
+            km = km_of(name)
+            if km == 0:
+                role = GEMM_ROLES[n_gemm0 % 3] if (reps == 0 or n_gemm0 < 3 * reps) else "gemm_fprop_none"
+                n_gemm0 += 1
+            else:
+                role = {2: "gemm_dgrad_none", 3: "gemm_wgrad_none"}.get(km)
         elif "cast_transpose_tile_kernel" in name:
             role = CT_SETUP[n_ct] if n_ct < 3 else CT_ROLES[(n_ct - 3) % 2]
             n_ct += 1
+        elif "cast_flat_kernel" in name:
+            role = ("setup_cast_x", "setup_cast_w", "setup_cast_dy")[n_flat] if n_flat < 3 else ("cast_x", "cast_dy")[(n_flat - 3) % 2]
+            n_flat += 1
         else:
             continue
-        per.setdefault(role, []).append(float(value))
+        if role is not None:
+            per.setdefault(role, []).append(float(value))
     return per
 
 

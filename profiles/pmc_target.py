@@ -19,8 +19,8 @@ w = (torch.randn(N, K, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat1
 dy = (torch.randn(M, N, device=dev, dtype=torch.float32) * 1e-2).to(torch.bfloat16)
 
 
-def quantizer(scale, dt):
-    return Float8Quantizer(torch.full((1,), scale, device=dev), torch.zeros(1, device=dev), dt)
+def quantizer(scale, dt, columnwise=True):
+    return Float8Quantizer(torch.full((1,), scale, device=dev), torch.zeros(1, device=dev), dt, columnwise=columnwise)
 
 
 qx, qw, qg = quantizer(64.0, DType.kFloat8E4M3), quantizer(2048.0, DType.kFloat8E4M3), quantizer(65536.0, DType.kFloat8E5M2)
@@ -30,6 +30,13 @@ ody = qg.make_empty(dy.shape, dtype=dy.dtype, device=dev)
 y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 dx = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
 dw = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
+# the step without FP8 transposes (LinearFP8State fp8_transposes="none", the library default): row-wise casts,
+# dgrad / wgrad read the row-wise payloads K-major
+rx, rw, rg = (quantizer(64.0, DType.kFloat8E4M3, False), quantizer(2048.0, DType.kFloat8E4M3, False),
+              quantizer(65536.0, DType.kFloat8E5M2, False))
+x8r, w8r, dy8r = rx(x), rw(w), rg(dy)
+oxr = rx.make_empty(x.shape, dtype=x.dtype, device=dev)
+odyr = rg.make_empty(dy.shape, dtype=dy.dtype, device=dev)
 torch.cuda.synchronize()
 for _ in range(reps):
     qx.update_quantized(x, ox)                                   # cast_transpose X   (e4m3)
@@ -37,5 +44,12 @@ for _ in range(reps):
     qg.update_quantized(dy, ody)                                 # cast_transpose dY  (e5m2)
     general_gemm(w8, dy8, layout="NN", out=dx, grad=True)        # dgrad
     general_gemm(x8, dy8, layout="NT", out=dw, grad=True)        # wgrad
+torch.cuda.synchronize()
+for _ in range(reps):
+    rx.update_quantized(x, oxr)                                  # cast X (row-wise only)
+    general_gemm(w8r, x8r, layout="TN", out=y)                   # fprop (the same kernel as above)
+    rg.update_quantized(dy, odyr)                                # cast dY
+    general_gemm(w8r, dy8r, layout="NN", out=dx, grad=True)      # dgrad, W read K-major     (kernel variant KM = 2)
+    general_gemm(x8r, dy8r, layout="NT", out=dw, grad=True)      # wgrad, X and dY K-major   (KM = 3)
 torch.cuda.synchronize()
 print("pmc_target done", reps)

@@ -9,8 +9,8 @@ sys.path.insert(0, %r)
 import torch
 from transformer_engine_amd.tensor import DType, Float8Quantizer, MXFP8Quantizer
 from transformer_engine_amd.gemm import general_gemm
-def q8(x, dt=DType.kFloat8E4M3, s=1.0):
-    return Float8Quantizer(torch.full((1,), s, device="cuda"), torch.zeros(1, device="cuda"), dt)(x)
+def q8(x, dt=DType.kFloat8E4M3, s=1.0, columnwise=True):
+    return Float8Quantizer(torch.full((1,), s, device="cuda"), torch.zeros(1, device="cuda"), dt, columnwise=columnwise)(x)
 tok, hid, ffn = 8192, 4096, 14336
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn(tok, hid, device="cuda", dtype=torch.bfloat16, generator=g)
@@ -25,7 +25,12 @@ o8 = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
 xs = q8(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g)); wsm = q8(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g))
 qms = MXFP8Quantizer(DType.kFloat8E4M3); qms.optimize_for_gemm = True
 xsm, wsmm = qms(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g)), qms(torch.randn(8192, 256, device="cuda", dtype=torch.bfloat16, generator=g))
-fns = {"k256": lambda: general_gemm(wsm, xs, layout="TN", out=o8), "mxk256": lambda: general_gemm(wsmm, xsm, layout="TN", out=o8), "fprop": lambda: general_gemm(wq, xq, layout="TN", out=y), "dgrad": lambda: general_gemm(wq, dyq, layout="NN", out=dx),
+xr, wr, dyr = q8(x, s=64.0, columnwise=False), q8(w, s=2048.0, columnwise=False), q8(dy, DType.kFloat8E5M2, 65536.0, columnwise=False)
+qmr = MXFP8Quantizer(DType.kFloat8E4M3, columnwise=True); qmr.optimize_for_gemm = True
+amr, bmr = qmr(a8), qmr(b8)    # reference layout: columnwise payload un-transposed
+fns = {"dgrad_km": lambda: general_gemm(wr, dyr, layout="NN", out=dx), "wgrad_km": lambda: general_gemm(xr, dyr, layout="NT", out=dw),
+       "mxNN": lambda: general_gemm(amr, bmr, layout="NN", out=o8), "mxNT": lambda: general_gemm(amr, bmr, layout="NT", out=o8),
+       "k256": lambda: general_gemm(wsm, xs, layout="TN", out=o8), "mxk256": lambda: general_gemm(wsmm, xsm, layout="TN", out=o8), "fprop": lambda: general_gemm(wq, xq, layout="TN", out=y), "dgrad": lambda: general_gemm(wq, dyq, layout="NN", out=dx),
        "wgrad": lambda: general_gemm(xq, dyq, layout="NT", out=dw), "mx8192": lambda: general_gemm(am, bm, layout="TN", out=o8)}
 t0 = time.time()
 while time.time() - t0 < 1.0:

@@ -354,16 +354,18 @@ def test_fp8_gemm_reads_rowwise_payloads_k_major_exact(M, N, K, fa, fb):
         assert torch.equal(got, dw_t), name
 
 
-def test_linear_without_input_and_weight_transposes_equals_default():
+@pytest.mark.parametrize("mode", ["grad_output", "none"])
+def test_linear_without_input_and_weight_transposes_equals_default(mode):
     """LinearFP8State(fp8_transposes="grad_output"): X and W are cast row-wise only (3 B/element, no X^T / W^T in memory),
-    dgrad / wgrad read them K-major; outputs and recipe state bit-equal to the default path over 3 steps."""
+    dgrad / wgrad read them K-major; "none": dY too (wgrad reads both operands K-major).  Outputs and recipe state
+    bit-equal to the default path over 3 steps."""
     from transformer_engine_amd import linear as L
     from transformer_engine_amd.recipe import DelayedScaling
     M, K, N = 768, 512, 1024
     g = torch.Generator().manual_seed(21)
     w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
-    sa = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"))
-    sb = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"), fp8_transposes="grad_output")
+    sa = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"), fp8_transposes="all")
+    sb = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"), fp8_transposes=mode)
     for it in range(3):
         x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
         dy = (torch.randn(M, N, generator=g) * 0.01).to(torch.bfloat16).cuda()

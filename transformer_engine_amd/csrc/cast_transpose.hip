@@ -236,31 +236,49 @@ __global__ __launch_bounds__(256) void cast_transpose_general_kernel(
 }
 
 // ---------------------------------------------------------------- flat rowwise cast (aligned, FP8 out)
-// Each thread converts 16 consecutive elements per step: two 16 B loads (bf16/fp16) and
-// one 16 B store; grid-stride over the tensor.  N % 16 == 0 and 16 B aligned pointers.
+// 3 B/element (bf16 in).  The tensor is a list of 8-element chunks (16 bytes in, 8 bytes out for bf16); a workgroup
+// takes 4 x 256 consecutive chunks per step, thread t chunks t, t + 256, t + 512, t + 768 of them: every load
+// instruction of a wave covers 1 KiB of consecutive input, every store 512 bytes of consecutive output.  As in the
+// tile kernel the loads of the NEXT step are issued before this step is converted and stored, so a workgroup keeps
+// 32 KiB of loads in flight.  N % 8 == 0, 16-byte aligned input, 8-byte aligned output.
+constexpr int kFlatUnroll = 4;
 template <typename IT, Fp8 F>
 __global__ __launch_bounds__(256) void cast_flat_kernel(
     const IT *__restrict__ in, const float *__restrict__ noop, uint8_t *__restrict__ out,
     const float *__restrict__ scale_ptr, float *__restrict__ amax_ptr,
-    float *__restrict__ scale_inv_ptr, const size_t n16) {
+    float *__restrict__ scale_inv_ptr, const size_t n8) {
   if (noop_set(noop)) return;
   __shared__ float red[4];
   const float scale = scale_ptr ? *scale_ptr : 1.0f;
   float amax = 0.f;
-  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += stride) {
-    float f[16];
-    Load8<IT>::run(in + i * 16, reinterpret_cast<float(&)[8]>(f[0]));
-    Load8<IT>::run(in + i * 16 + 8, reinterpret_cast<float(&)[8]>(f[8]));
-    u32x4 o;
+  constexpr size_t kStep = 256 * kFlatUnroll;   // chunks per workgroup step
+  const size_t stride = static_cast<size_t>(gridDim.x) * kStep;
+  auto load_step = [&](size_t base, Raw8<IT> (&raw)[kFlatUnroll]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, __builtin_fabsf(f[4 * k + j]));
-      o[k] = cvt4_fp8<F>(f[4 * k] * scale, f[4 * k + 1] * scale, f[4 * k + 2] * scale,
-                         f[4 * k + 3] * scale);
+    for (int u = 0; u < kFlatUnroll; ++u) {
+      const size_t c = base + u * 256 + threadIdx.x;
+      raw[u] = Raw8<IT>::load(in + (c < n8 ? c : n8 - 1) * 8);   // clamped, the value is dropped at use
     }
-    *reinterpret_cast<u32x4 *>(out + i * 16) = o;
+  };
+  Raw8<IT> cur[kFlatUnroll], nxt[kFlatUnroll];
+  size_t base = static_cast<size_t>(blockIdx.x) * kStep;
+  if (base < n8) load_step(base, cur);
+  for (; base < n8; base += stride) {
+    if (base + stride < n8) load_step(base + stride, nxt);
+#pragma unroll
+    for (int u = 0; u < kFlatUnroll; ++u) {
+      const size_t c = base + u * 256 + threadIdx.x;
+      float f[8];
+      cur[u].widen8(f);
+      if (c >= n8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      }
+      const u32x2 w = quantize8<F>(f, scale, amax);   // amax of the unscaled values, sat(f * scale)
+      if (c < n8) *reinterpret_cast<u32x2 *>(out + c * 8) = w;
+    }
+#pragma unroll
+    for (int u = 0; u < kFlatUnroll; ++u) cur[u] = nxt[u];
   }
   if (amax_ptr != nullptr) {
     amax = block_max<4>(amax, red);
@@ -371,12 +389,22 @@ bool tile_path_ok(const Tensor &in, const Tensor &out, size_t rows, size_t cols)
          aligned16(out.data.ptr) && aligned16(out.columnwise_data.ptr);
 }
 
+// Workgroups per CU of the flat cast (NVTE_AMD_CAST_WGS_PER_CU overrides, tuning aid).  Measured on the configs[1]
+// tensors, isolated (scratch/perf_cast_flat.py): dY [8192, 14336] 66 / 60 / 58 / 58 us and X [8192, 4096] 22.8 / 19.8 /
+// 19.7 / 19.6 us at 2 / 4 / 6 / 8 workgroups per CU (the grid-stride kernel it replaces: 63-70 and 21.7 us).
+unsigned flat_grid(size_t steps) {
+  static const unsigned per_cu = [] {
+    const char *e = std::getenv("NVTE_AMD_CAST_WGS_PER_CU");
+    const int v = e ? std::atoi(e) : 0;
+    return static_cast<unsigned>(v >= 1 && v <= 16 ? v : 6);
+  }();
+  return static_cast<unsigned>(std::min<size_t>(steps, static_cast<size_t>(device_info().num_cus) * per_cu));
+}
+
 template <typename IT, Fp8 F>
 void launch_flat(const Tensor &in, const float *noop, Tensor &out, size_t n, hipStream_t stream) {
-  const size_t n16 = n / 16;
-  const DeviceInfo &di = device_info();
-  const size_t want = ceil_div(n16, 256);
-  const unsigned grid = static_cast<unsigned>(std::min<size_t>(want, static_cast<size_t>(di.num_cus) * 8));
+  const size_t n16 = n / 8;   // 8-element chunks
+  const unsigned grid = flat_grid(ceil_div(n16, static_cast<size_t>(256 * kFlatUnroll)));
   hipLaunchKernelGGL((cast_flat_kernel<IT, F>), dim3(grid), dim3(256), 0, stream,
                      static_cast<const IT *>(in.data.ptr), noop, static_cast<uint8_t *>(out.data.ptr),
                      static_cast<const float *>(out.scale.ptr), static_cast<float *>(out.amax.ptr),
@@ -488,7 +516,7 @@ void cast_rowwise_launch(const Tensor &in, const float *noop, Tensor &out, hipSt
   NVTE_REQUIRE_DATA(in.data, "cast input");
   NVTE_REQUIRE_DATA(out.data, "cast output");
   const bool fp8_out = is_fp8(out.data.dtype);
-  const bool fast = fp8_out && n % 16 == 0 && aligned16(in.data.ptr) && aligned16(out.data.ptr);
+  const bool fast = fp8_out && n % 8 == 0 && aligned16(in.data.ptr) && aligned16(out.data.ptr);
   TE_SWITCH_IN(in.data.dtype, IT, {
     if (fast) {
       if (out.data.dtype == kNVTEFloat8E4M3)

@@ -209,6 +209,42 @@ __device__ __forceinline__ void store_any(void *p, size_t idx, int dtype, float 
   }
 }
 
+// LDS-DMA (buffer_load ... lds) issued from inline assembly.  The compiler's own form of the instruction
+// (__builtin_amdgcn_raw_ptr_buffer_load_lds) makes its wait-count pass treat EVERY later LDS store - and the transposing
+// LDS loads of the K-major variants, which it models as stores - as a possible read of the DMA's destination: it then puts
+// an s_waitcnt vmcnt(0), a wait for the K tile staged a moment ago, in front of them (4 per K tile in the K-major kernels,
+// one at the start of every epilogue).  The kernel orders DMA against LDS reads itself (vmcnt + s_barrier at the K-tile
+// hand-over), so the instruction is hidden from that pass
+// in the kernel variants where that pays (kAsmDma in the kernel); TE_GEMM_BUILTIN_DMA forces the builtin everywhere (A/B builds).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_t make_rsrc(const void *base, unsigned bytes) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  return v4i_t{static_cast<int>(static_cast<uint32_t>(b)), static_cast<int>(static_cast<uint32_t>(b >> 32) & 0xFFFFu),
+               static_cast<int>(bytes), 0x00020000};
+}
+// 64 lanes x 16 bytes -> LDS [lds_addr, lds_addr + 1024); source byte = rsrc base + voff (per lane) + soff
+// (the scalar operands are wave-uniform by construction; readfirstlane makes that known where the values come out of
+// memory - the grouped kernels' member descriptors - and folds away elsewhere)
+__device__ __forceinline__ v4i_t uniform4(const v4i_t r) {
+  return v4i_t{__builtin_amdgcn_readfirstlane(r[0]), __builtin_amdgcn_readfirstlane(r[1]),
+               __builtin_amdgcn_readfirstlane(r[2]), __builtin_amdgcn_readfirstlane(r[3])};
+}
+__device__ __forceinline__ void glds_b128(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  rsrc = uniform4(rsrc);
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// 64 lanes x 4 bytes -> LDS [lds_addr, lds_addr + 256)
+__device__ __forceinline__ void glds_b32(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  rsrc = uniform4(rsrc);
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  soff = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
 // Main-loop pipeline:
 //  * every MFMA fragment register is refilled from LDS right after its last use, 5..7 MFMAs
 //    before its next one, so the matrix pipe never waits on LDS; LDS and global->LDS
@@ -247,6 +283,15 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // Compile-time on purpose: a run-time branch in the main loop lets the scheduler tear up the pinned MFMA order
   // (measured: 300-430 spilled registers, 8x slower).
   constexpr bool PKM = (KM & 1) != 0, QKM = (KM & 2) != 0, PKC = PKM && (KM & 4) != 0, QKC = QKM && (KM & 8) != 0;
+  // Which form of the LDS-DMA instruction stages the operands (see glds_b128): the assembly form where the compiler's
+  // waits cost more than its extra scalar instructions do - both operands K-major (wgrad: 463 -> 371 us per-tensor, 511 ->
+  // 442 us MXFP8 at the configs[1] / 8192^3 shapes) and the per-tensor dgrad (346 -> 336 us); the builtin form where
+  // they do not (K-contiguous operands: 2 % faster with the builtin; MXFP8 with only Q K-major: 3 %).
+#ifdef TE_GEMM_BUILTIN_DMA
+  constexpr bool kAsmDma = false;
+#else
+  constexpr bool kAsmDma = PKM || (!MX && QKM);
+#endif
   // LDS map: [0, 128 KiB) two K-tile slots | MX only: 2 x 2 KiB scale slots | epilogue staging
   constexpr int kScaleBase = 2 * kStageBytes;
   constexpr int kEpiBase = kScaleBase + (MX ? 2 * kScaleSlotBytes : 0);
@@ -451,23 +496,42 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     uint8_t *base = lds + slot * kStageBytes;
     const unsigned soff = (wave * 4 + q) * 8 * (GROUPED ? t.k : a.k) + k0;
     lds_u8 *dst_p = (lds_u8 *)(base + (wave * 4 + q) * 1024);
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
-    if constexpr (PKM)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16,
-                                               km_voffP + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldP, 0, kStageAux);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, kStageAux);
+    if constexpr (!kAsmDma) {
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(t.pbase, 0, t.pbytes, 0x00020000);
+      if constexpr (PKM)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16,
+                                                 km_voffP + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldP, 0, kStageAux);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (__attribute__((address_space(3))) void *)dst_p, 16, voff[q & 1], soff, 0, kStageAux);
+    } else {
+      static_assert(!kAsmDma || kStageAux == 0, "cache-policy experiments need the builtin form (TE_GEMM_BUILTIN_DMA)");
+      const v4i_t rp = make_rsrc(t.pbase, t.pbytes);
+      const unsigned la = static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst_p));
+      if constexpr (PKM)
+        glds_b128(rp, la, km_voffP + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldP);
+      else
+        glds_b128(rp, la, voff[q & 1], soff);
+    }
   };
   auto stage_Q = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
     uint8_t *base = lds + slot * kStageBytes;
     const unsigned soff = (wave * 4 + q) * 8 * (GROUPED ? t.k : a.k) + k0;
     lds_u8 *dst_q = (lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024);
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(t.qbase, 0, t.qbytes, 0x00020000);
-    if constexpr (QKM)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16,
-                                               km_voffQ + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldQ, 0, kStageAux);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, kStageAux);
+    if constexpr (!kAsmDma) {
+      const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(t.qbase, 0, t.qbytes, 0x00020000);
+      if constexpr (QKM)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16,
+                                                 km_voffQ + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldQ, 0, kStageAux);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void *)dst_q, 16, voff[q & 1], soff, 0, kStageAux);
+    } else {
+      const v4i_t rq = make_rsrc(t.qbase, t.qbytes);
+      const unsigned la = static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst_q));
+      if constexpr (QKM)
+        glds_b128(rq, la, km_voffQ + (q & 1) * km_flip, (k0 + (wave * 4 + q) * 4) * a.ldQ);
+      else
+        glds_b128(rq, la, voff[q & 1], soff);
+    }
   };
   auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
     stage_P(t, slot, k0, q, voff);
@@ -606,12 +670,18 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   const unsigned e_step = e_swz ? 512u : (e_kc ? 4u * e_stride : 4u);
   auto stage_scales = [&](const TileCtx &t, unsigned slot, unsigned kt) {
     if constexpr (MX) {
-      const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<uint8_t *>(GROUPED ? t.eb : e_base), 0, GROUPED ? t.ebytes : e_bytes, 0x00020000);
       lds_u8 *dst = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + wave * 256);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4,
-                                               GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv,
-                                               t.ss + kt * e_step, 0, 0);
+      if constexpr (!kAsmDma) {
+        const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t *>(GROUPED ? t.eb : e_base), 0, GROUPED ? t.ebytes : e_bytes, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4,
+                                                 GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv,
+                                                 t.ss + kt * e_step, 0, 0);
+      } else {
+        glds_b32(make_rsrc(GROUPED ? t.eb : e_base, GROUPED ? t.ebytes : e_bytes),
+                 static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst)),
+                 GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv, t.ss + kt * e_step);
+      }
     }
   };
   // Pick this wave's scale dwords of K tile `kt` (already in scale slot `slot`) and pre-shift so

@@ -401,7 +401,7 @@ class ColumnParallelLinearSP:
         self.weight = (torch.randn(self.N_local, in_features, generator=g) * 0.02).to(params_dtype).to(self.device)
         # the gathered operand keeps compact MXFP8 scales (ref module/linear.py:2069)
         # (MXFP8: the gathered operand's columnwise pair travels in the transposed layout, _all_gather_mxfp8)
-        self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device, compact_mx_scales=("input",),
+        self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device, compact_mx_scales=("input",), fp8_transposes="all",
                                     mx_columnwise="transposed")
         self.overlap = overlap
         self.chunks = chunks
@@ -680,7 +680,7 @@ class RowParallelLinearSP:
         g = torch.Generator(device="cpu").manual_seed(8765 + rank)
         self.weight = (torch.randn(out_features, self.K_local, generator=g) * 0.02).to(params_dtype).to(self.device)
         # the gathered operand keeps compact MXFP8 scales (ref module/linear.py:2077)
-        self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device, compact_mx_scales=("grad_output",),
+        self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device, compact_mx_scales=("grad_output",), fp8_transposes="all",
                                     mx_columnwise="transposed")
         self.overlap, self.chunks, self.out_dtype = overlap, chunks, params_dtype
         # dY is sharded on tokens and gathered in FP8: one scale over the whole group

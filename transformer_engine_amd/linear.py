@@ -66,14 +66,19 @@ def bgrad_quantize(dy: torch.Tensor, quantizer):
 
 # which MXFP8 columnwise layout the module states ask the quantize kernels for (measured on the configs[2] step,
 # DESIGN 6c); both run through the same GEMM entry point
-MX_COLUMNWISE_DEFAULT = "transposed"
+MX_COLUMNWISE_DEFAULT = "reference"
+# which per-tensor FP8 tensors of a Linear keep a transposed copy for the backward GEMMs: "none" - the GEMM reads
+# row-wise payloads K-major at 96-99 % of the K-contiguous rate, the casts move 3 instead of 4 bytes per element and
+# the configs[1] step is 7 % faster; "all" is the reference's data flow on hardware without non-TN FP8
+# GEMMs.  Outputs and recipe state are bit-equal either way.
+FP8_TRANSPOSES_DEFAULT = "none"
 
 
 class LinearFP8State:
     """Per-module quantization state: recipe states + quantizers for one Linear."""
 
     def __init__(self, recipe, device=None, compact_mx_scales=(), mx_columnwise: Optional[str] = None,
-                 fp8_transposes: str = "all"):
+                 fp8_transposes: Optional[str] = None):
         """compact_mx_scales: which of "input", "weight", "grad_output" keep their MXFP8 scales in the compact
         layout (the others are written GEMM-swizzled, see below).
         mx_columnwise: layout of the MXFP8 columnwise copies that dgrad / wgrad read - "reference" (the payload keeps
@@ -84,8 +89,12 @@ class LinearFP8State:
         # behaviour where non-TN FP8 GEMMs are unsupported (input, weight, grad_output).  "grad_output": only dY - dgrad
         # and wgrad then read the ROW-WISE payloads of W and X K-major (one K-major operand per GEMM, the rate of the
         # K-contiguous kernel), X is cast at 3 instead of 4 bytes per element and neither X^T nor W^T is ever stored.
-        if fp8_transposes not in ("all", "grad_output"):
-            raise ValueError("fp8_transposes must be 'all' or 'grad_output'")
+        # "none": dY is cast row-wise only as well; wgrad then reads BOTH operands K-major (3-4 % slower than the
+        # K-contiguous wgrad) and no FP8 transpose exists anywhere in the layer.
+        # Default: NVTE_AMD_FP8_TRANSPOSES, else FP8_TRANSPOSES_DEFAULT.
+        fp8_transposes = fp8_transposes or os.environ.get("NVTE_AMD_FP8_TRANSPOSES") or FP8_TRANSPOSES_DEFAULT
+        if fp8_transposes not in ("all", "grad_output", "none"):
+            raise ValueError("fp8_transposes must be 'all', 'grad_output' or 'none'")
         self.fp8_transposes = fp8_transposes
         self.recipe = recipe
         self.device = device or torch.device("cuda")
@@ -152,7 +161,7 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     """Returns (y, saved) where saved = (x8, w8) for the backward pass."""
     qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
     # per-tensor FP8 with fp8_transposes="grad_output": no transposed copies of X and W (read K-major in backward)
-    col = needs_backward and not (st.fp8_transposes == "grad_output" and not isinstance(qi, MXFP8Quantizer))
+    col = needs_backward and not (st.fp8_transposes != "all" and not isinstance(qi, MXFP8Quantizer))
     qi.set_usage(rowwise=True, columnwise=col)                     # linear.py:399-406
     x2d = x.reshape(-1, x.shape[-1])
     x8 = qi(x2d)                                                   # linear.py:407
@@ -176,7 +185,8 @@ def linear_backward(dy: torch.Tensor, saved, st: LinearFP8State, *, use_bias: bo
     """Returns (dx, dw, dbias)."""
     x8, w8 = saved
     qg = st.bwd_q[BWD_GRAD_OUTPUT]
-    qg.set_usage(rowwise=True, columnwise=True)                    # linear.py:874-876
+    # linear.py:874-876 (per-tensor FP8 with fp8_transposes="none": no dY^T either, wgrad reads dY K-major)
+    qg.set_usage(rowwise=True, columnwise=not (st.fp8_transposes == "none" and not isinstance(qg, MXFP8Quantizer)))
     dy2d = dy.reshape(-1, dy.shape[-1])
     dy2d = dy2d if dy2d.is_contiguous() else dy2d.contiguous()
     dbias = None
