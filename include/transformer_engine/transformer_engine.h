@@ -147,9 +147,12 @@ enum NVTEQuantizationConfigAttribute {
                                                            const void *buf, size_t size_in_bytes);
 /* ref :477 */ void nvte_destroy_quantization_config(NVTEQuantizationConfig config);
 
-/* ref :483.  Returns 0 on MI355X BY DESIGN: callers then materialise the
- * pre-transposed ("columnwise") FP8 copy, so all three Linear GEMMs reach the
- * MFMA kernel with K-contiguous operands ("TN everywhere"). */
+/* ref :483.  Returns 0 by default: callers then materialise the pre-transposed
+ * ("columnwise") FP8 copy and all three Linear GEMMs reach the MFMA kernel with
+ * K-contiguous operands.  Since round 3 the GEMM also reads row-wise payloads of
+ * non-TN operands K-major at 96-99 % of that rate: with
+ * NVTE_AMD_NON_TN_FP8_GEMM=1 in the environment this returns 1 and a framework
+ * may skip the transposes (casts at 3 instead of 4 bytes per element). */
 int nvte_is_non_tn_fp8_gemm_supported(void);
 
 /* ref :494 */ void nvte_memset(void *ptr, int value, size_t size_in_bytes, hipStream_t stream);

@@ -7,6 +7,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 import threading
 
 import pytest
@@ -256,7 +257,13 @@ def test_arena_is_thread_safe():
 
 
 def test_misc_entry_points():
-    assert api.nvte_is_non_tn_fp8_gemm_supported() == 0
+    assert api.nvte_is_non_tn_fp8_gemm_supported() == (1 if os.environ.get("NVTE_AMD_NON_TN_FP8_GEMM", "0") not in ("", "0") else 0)
+    # the opt-in answer, in a process of its own (the library reads the variable once)
+    code = ("import sys; sys.path.insert(0, %r); from transformer_engine_amd import _lib; "
+            "print(_lib.api.nvte_is_non_tn_fp8_gemm_supported())" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NVTE_AMD_NON_TN_FP8_GEMM="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip().endswith("1"), (out.stdout, out.stderr)
     assert api.nvte_get_num_compute_streams() == 4
     s = api.nvte_make_shape((C.c_size_t * 3)(2, 3, 4), 3)
     assert s.ndim == 3 and s.data[2] == 4

@@ -669,9 +669,18 @@ void nvte_tensor_pack_destroy(NVTETensorPack *pack) {
   });
 }
 
+// The GEMM reads row-wise FP8 payloads of a non-TN operand K-major (ds_read_b64_tr_b8) at 96-99 % of the K-contiguous
+// rate, so a framework may skip the transposed copies: NVTE_AMD_NON_TN_FP8_GEMM=1 makes this query say so (the reference's
+// Float8Quantizer then allocates no transpose, csrc/quantizer.cpp:342-356).  The default stays 0, the answer every caller
+// of rounds 1-2 was built against; this package's own Linear states skip the transposes either way
+// (LinearFP8State fp8_transposes, default "none").
 int nvte_is_non_tn_fp8_gemm_supported(void) {
   api_enter("nvte_is_non_tn_fp8_gemm_supported");
-  return 0;
+  static const int v = [] {
+    const char *e = std::getenv("NVTE_AMD_NON_TN_FP8_GEMM");
+    return (e != nullptr && std::atoi(e) != 0) ? 1 : 0;
+  }();
+  return v;
 }
 
 // ------------------------------------------------------------------ quantization config
