@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--gemm-cus", type=int, default=0,
                     help="cap the persistent GEMM grid at this many CUs (NVTE_EXT_MARGIN_SM of the reference: the rest is "
                          "left to the RCCL kernels of an overlapped step); 0 = all")
-    ap.add_argument("--fp8-transposes", default="none", choices=["none", "grad_output", "all"],
+    ap.add_argument("--fp8-transposes", default="none", choices=["none", "input", "grad_output", "all"],
                     help="which per-tensor FP8 tensors keep a transposed copy for the backward GEMMs (LinearFP8State): 'none' = "
                          "the library default (row-wise payloads read K-major by dgrad / wgrad), 'all' = the data flow of "
                          "rounds 1-2 (cast_transpose for X and dY); outputs are bit-equal")
@@ -153,10 +153,11 @@ def grouped_c5(dev, iters):
         step()
     ms_eager = time_kernel(step, iters)
     run, graphed = graph_of(step)
-    ms = time_kernel(run, iters) if graphed else ms_eager
+    ms_graph = time_kernel(run, iters) if graphed else None
+    ms = min(ms_eager, ms_graph) if graphed else ms_eager      # replay is not always faster: its missing gaps cost clock
     return {"workload": "8 experts 4096->14336, 16384 routed tokens, current scaling, fwd+bwd, 1 GPU",
             "m_splits": m_splits, "ms_per_step": ms, "tflops": 6.0 * M * N * K / (ms * 1e-3) / 1e12,
-            "hip_graph": graphed, "ms_per_step_eager": ms_eager}
+            "ms_per_step_hip_graph": ms_graph, "ms_per_step_eager": ms_eager}
 
 
 def mxfp8_c3(dev, iters):
@@ -179,10 +180,11 @@ def mxfp8_c3(dev, iters):
         step()
     ms_eager = time_kernel(step, iters)
     run, graphed = graph_of(step)
-    ms = time_kernel(run, iters) if graphed else ms_eager
+    ms_graph = time_kernel(run, iters) if graphed else None
+    ms = min(ms_eager, ms_graph) if graphed else ms_eager
     return {"workload": "Linear 8192->8192, 8192 tokens, MXFP8 block scaling (columnwise copies in the reference's own "
                         "layout, read K-major by dgrad / wgrad), fwd+bwd, 1 GPU",
-            "ms_per_step": ms, "tflops": 6.0 * M * N * K / (ms * 1e-3) / 1e12, "hip_graph": graphed,
+            "ms_per_step": ms, "tflops": 6.0 * M * N * K / (ms * 1e-3) / 1e12, "ms_per_step_hip_graph": ms_graph,
             "ms_per_step_eager": ms_eager}
 
 
@@ -531,7 +533,8 @@ def main():
         qi, qw, qg = st.fwd_q[L.FWD_INPUT], st.fwd_q[L.FWD_WEIGHT], st.bwd_q[L.BWD_GRAD_OUTPUT]
         mode = args.fp8_transposes
         # which tensors carry a transposed copy in the timed step (LinearFP8State.fp8_transposes)
-        cols = {"all": (True, True, True), "grad_output": (False, False, True), "none": (False, False, False)}
+        cols = {"all": (True, True, True), "grad_output": (False, False, True), "input": (True, False, False),
+                "none": (False, False, False)}
 
         def operands(flags):
             """FP8 X, W, dY (+ preallocated outputs of the same kind) with / without transposed copies."""
@@ -755,12 +758,14 @@ def main():
                            "operand K-contiguous",
                     "grad_output": "fp8_transposes='grad_output': no X^T / W^T, dgrad + wgrad read the row-wise payloads of "
                                    "W and X K-major (ds_read_b64_tr_b8)",
+                    "input": "fp8_transposes='input': only X^T is kept; dgrad reads W and wgrad reads dY K-major (one K-major "
+                             "operand per GEMM)",
                     "none": "fp8_transposes='none': X, W and dY are cast row-wise only (3 B/element, no FP8 transpose in "
                             "the layer), dgrad reads W and wgrad reads X and dY K-major"}
             result["extra"]["step_variants"] = {"note": "the same step with the other settings of LinearFP8State."
                                                         "fp8_transposes; outputs and recipe state are bit-equal "
                                                         "(tests/test_parity_r3_gpu.py); `value` is the '%s' one" % mode}
-            for other in ("all", "grad_output", "none"):
+            for other in ("all", "grad_output", "input", "none"):
                 ms_o = ms_per_step if other == mode else variant_step(other)
                 result["extra"]["step_variants"][other] = {"ms_per_step": ms_o, "tflops": flops_per_step / (ms_o * 1e-3) / 1e12,
                                                            "what": what[other]}

@@ -6,7 +6,8 @@ python - <<'PY'
 import json
 d=json.loads(open("gpurun_out/bench_variants.json").read().strip().splitlines()[-1])
 print("all:", round(d["ms_per_step"],4), "frac", round(d["roofline"]["frac"],4))
-for k in ("step_rowwise_x_and_w","step_no_fp8_transposes"):
-    print(k, round(d["extra"][k]["ms_per_step"],4))
+for k in ():
+    pass
+print({k: round(v["ms_per_step"],4) for k,v in d["extra"]["step_variants"].items() if isinstance(v,dict)})
 print(d["extra"]["step_breakdown"])
 PY

@@ -354,7 +354,7 @@ def test_fp8_gemm_reads_rowwise_payloads_k_major_exact(M, N, K, fa, fb):
         assert torch.equal(got, dw_t), name
 
 
-@pytest.mark.parametrize("mode", ["grad_output", "none"])
+@pytest.mark.parametrize("mode", ["grad_output", "input", "none"])
 def test_linear_without_input_and_weight_transposes_equals_default(mode):
     """LinearFP8State(fp8_transposes="grad_output"): X and W are cast row-wise only (3 B/element, no X^T / W^T in memory),
     dgrad / wgrad read them K-major; "none": dY too (wgrad reads both operands K-major).  Outputs and recipe state
@@ -376,7 +376,7 @@ def test_linear_without_input_and_weight_transposes_equals_default(mode):
             st.update_fwd_bwd()
             outs.append((y, dx, dw, saved))
         torch.cuda.synchronize()
-        assert outs[1][3][0]._transpose is None and outs[1][3][1]._transpose is None     # no X^T, no W^T
+        assert (outs[1][3][0]._transpose is None) == (mode != "input") and outs[1][3][1]._transpose is None   # no X^T (but "input"), no W^T
         assert outs[0][3][0]._transpose is not None
         for a, b in zip(outs[0][:3], outs[1][:3]):
             assert torch.equal(a, b), it

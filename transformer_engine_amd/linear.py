@@ -93,8 +93,9 @@ class LinearFP8State:
         # K-contiguous wgrad) and no FP8 transpose exists anywhere in the layer.
         # Default: NVTE_AMD_FP8_TRANSPOSES, else FP8_TRANSPOSES_DEFAULT.
         fp8_transposes = fp8_transposes or os.environ.get("NVTE_AMD_FP8_TRANSPOSES") or FP8_TRANSPOSES_DEFAULT
-        if fp8_transposes not in ("all", "grad_output", "none"):
-            raise ValueError("fp8_transposes must be 'all', 'grad_output' or 'none'")
+        # "input": only X^T (the smallest of the three) - wgrad then has ONE K-major operand (dY) like dgrad (W).
+        if fp8_transposes not in ("all", "grad_output", "input", "none"):
+            raise ValueError("fp8_transposes must be 'all', 'grad_output', 'input' or 'none'")
         self.fp8_transposes = fp8_transposes
         self.recipe = recipe
         self.device = device or torch.device("cuda")
@@ -161,8 +162,10 @@ def linear_forward(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     """Returns (y, saved) where saved = (x8, w8) for the backward pass."""
     qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
     # per-tensor FP8 with fp8_transposes="grad_output": no transposed copies of X and W (read K-major in backward)
-    col = needs_backward and not (st.fp8_transposes != "all" and not isinstance(qi, MXFP8Quantizer))
-    qi.set_usage(rowwise=True, columnwise=col)                     # linear.py:399-406
+    per_tensor = not isinstance(qi, MXFP8Quantizer)
+    col = needs_backward and not (st.fp8_transposes != "all" and per_tensor)
+    col_x = needs_backward and not (st.fp8_transposes in ("grad_output", "none") and per_tensor)
+    qi.set_usage(rowwise=True, columnwise=col_x)                   # linear.py:399-406
     x2d = x.reshape(-1, x.shape[-1])
     x8 = qi(x2d)                                                   # linear.py:407
     # weight: quantize on the first microbatch (or always when no caching was requested)
@@ -186,7 +189,7 @@ def linear_backward(dy: torch.Tensor, saved, st: LinearFP8State, *, use_bias: bo
     x8, w8 = saved
     qg = st.bwd_q[BWD_GRAD_OUTPUT]
     # linear.py:874-876 (per-tensor FP8 with fp8_transposes="none": no dY^T either, wgrad reads dY K-major)
-    qg.set_usage(rowwise=True, columnwise=not (st.fp8_transposes == "none" and not isinstance(qg, MXFP8Quantizer)))
+    qg.set_usage(rowwise=True, columnwise=not (st.fp8_transposes in ("none", "input") and not isinstance(qg, MXFP8Quantizer)))
     dy2d = dy.reshape(-1, dy.shape[-1])
     dy2d = dy2d if dy2d.is_contiguous() else dy2d.contiguous()
     dbias = None
