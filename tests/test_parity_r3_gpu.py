@@ -247,13 +247,18 @@ def test_recipe_update_fwd_bwd_in_one_launch_equals_two_calls():
 
 
 # ------------------------------------------------------------------------------------------ GroupedLinear, delayed scaling + list path
+@pytest.mark.parametrize("grouped_transposes", ["none", "all"])
 @pytest.mark.parametrize("recipe_name", ["delayed", "current", "mxfp8"])
-def test_grouped_linear_recipes_grouped_path_list_path_and_per_expert_linear(recipe_name):
+def test_grouped_linear_recipes_grouped_path_list_path_and_per_expert_linear(recipe_name, grouped_transposes):
     """GroupedLinear under DelayedScaling (one scale / amax history per expert and operand, ref
     module/grouped_linear.py quantizer layout), current scaling and MXFP8, three ways over 3 steps:
     the grouped path (device-side splits), the legacy list path (host m_splits, split_quantize + nvte_multi_tensor_gemm,
     ref module/grouped_linear.py:630-697) and one te.Linear-style state per expert.  Same quantization, same kernel
-    arithmetic: outputs, scales and amax histories bit-equal."""
+    arithmetic: outputs, scales and amax histories bit-equal.  grouped_transposes: the grouped path with per-member
+    transposed copies ("all") or without any ("none", the default: the grouped dgrad / wgrad kernels read the row-wise
+    payloads K-major); the list path keeps its transposes and the per-expert Linear states none."""
+    if recipe_name == "mxfp8" and grouped_transposes == "none":
+        pytest.skip("MXFP8 members always keep their transposed columnwise copies")
     from transformer_engine_amd.grouped_linear import (GroupedLinearFP8State, grouped_linear_backward,
                                                        grouped_linear_backward_list, grouped_linear_forward,
                                                        grouped_linear_forward_list)
@@ -268,7 +273,8 @@ def test_grouped_linear_recipes_grouped_path_list_path_and_per_expert_linear(rec
     w = (torch.randn(G * N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
     ws = [w[i * N:(i + 1) * N].contiguous() for i in range(G)]
     fd = torch.tensor(m_splits, dtype=torch.int64, device="cuda")
-    st_g, st_l = GroupedLinearFP8State(mk(), G), GroupedLinearFP8State(mk(), G)
+    st_g, st_l = GroupedLinearFP8State(mk(), G, fp8_transposes=grouped_transposes), GroupedLinearFP8State(mk(), G)
+    assert st_g.keep_transposes == (grouped_transposes == "all" or recipe_name == "mxfp8")
     st_e = [LinearFP8State(mk()) for _ in range(G)]
     for it in range(3):
         x = (torch.randn(M, K, generator=g) * (1.0 + it)).to(torch.bfloat16).cuda()

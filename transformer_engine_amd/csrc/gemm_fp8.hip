@@ -276,7 +276,7 @@ template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool M
           int KM = 0>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   static_assert(!(GROUPED && EPI), "the grouped variant has no extended epilogues");
-  static_assert(KM == 0 || (!GROUPED && !EPI), "K-major operands: the plain (un-grouped, basic epilogue) kernels only");
+  static_assert(KM == 0 || (!EPI && !(GROUPED && MX)), "K-major operands: basic epilogue; grouped launches per-tensor FP8 only");
   static_assert(MX || (KM & 12) == 0, "scale-layout bits belong to the MXFP8 variants");
   // bits 2 / 3: that K-major operand's e8m0 scales are COMPACT, i.e. stored [k block][row] like the payload (the
   // reference's columnwise scale matrix); otherwise GEMM-swizzled, one format whatever the quantization direction.
@@ -409,6 +409,17 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
       t.qbase = const_cast<uint8_t *>(d.Q) + static_cast<size_t>(t.j0) * d.k;
       t.pbytes = rows_p * d.k;
       t.qbytes = rows_q * d.k;
+      // K-major member (its row-wise payload, contracted over its rows; every member has the launch's row length
+      // a.ldP / a.ldQ): the descriptor starts at the tile's first row inside k-row 0 and ends with the member
+      // (a member without rows - an expert without tokens - has k = 0: empty descriptors, its output is zero)
+      if constexpr (PKM) {
+        t.pbase = const_cast<uint8_t *>(d.P) + t.i0;
+        t.pbytes = (valid && d.k != 0) ? d.k * a.ldP - t.i0 : 0u;
+      }
+      if constexpr (QKM) {
+        t.qbase = const_cast<uint8_t *>(d.Q) + t.j0;
+        t.qbytes = (valid && d.k != 0) ? d.k * a.ldQ - t.j0 : 0u;
+      }
       if constexpr (MX) {
         const GroupScaleDesc &sd = a.group_scales[grp];
         const unsigned stride = wave < 4 ? sd.eP_stride : sd.eQ_stride;
@@ -1113,6 +1124,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
 #define TE_GEMM_VARIANTS(X)                                                                         \
   X(false, false, false, 0) X(false, true, false, 0) X(true, false, false, 0) X(true, true, false, 0) \
   X(false, false, true, 0) X(true, false, true, 0)                                                  \
+  X(false, false, true, 1) X(false, false, true, 2) X(false, false, true, 3)                        \
   X(false, false, false, 1) X(false, false, false, 2) X(false, false, false, 3)                     \
   X(true, false, false, 2) X(true, false, false, 10) X(true, false, false, 3) X(true, false, false, 7) \
   X(true, false, false, 11) X(true, false, false, 15)
@@ -1552,6 +1564,8 @@ struct GroupedOperandMeta {
   const float *scale_inv = nullptr;  // per-tensor scaling: one entry per member
   const uint8_t *e8m0 = nullptr;     // MXFP8: the members' scale matrices back to back
   int k_is_last = 1;                 // MXFP8: 1 = rowwise storage, 0 = per-member transposed columnwise
+  int k_major = 0;                   // per-tensor FP8: the row-wise payload of an operand contracted over its rows
+  unsigned ld = 0;                   // ... and its row length (bytes between consecutive k), one for all members
   GroupShapes shapes;
 };
 struct GroupedOutMeta {
@@ -1753,8 +1767,11 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     // the stores follow D's own shape; anything inconsistent (or a K the 16-byte loads cannot take)
     // turns the member's output into NaN instead of reading out of bounds
     if (mx) mx_bad_run |= (a_first % 128 != 0 || b_first % 128 != 0) ? 1u : 0u;
+    // K-major operands are staged in 16-byte units along their rows, inside 32-bit descriptors
+    const bool km_ok = (!B.k_major || (n % 16 == 0 && static_cast<uint64_t>(kb) * B.ld < (1ull << 32))) &&
+                       (!A.k_major || (m % 16 == 0 && static_cast<uint64_t>(ka) * A.ld < (1ull << 32)));
     const bool ok = d_first == n && d_last == m && ka == kb && ka % (mx ? 32 : 16) == 0 && ka <= (1 << 23) &&
-                    mx_bad_run == 0;
+                    mx_bad_run == 0 && km_ok;
     GroupDesc d;
     d.P = B.base + b_off;
     d.Q = q_ptr;
@@ -1805,6 +1822,18 @@ GroupedOperandMeta pick_grouped_operand(const GroupedTensor &t, bool k_is_last, 
     m.base = static_cast<const uint8_t *>(t.data.ptr);
     sinv = t.scale_inv.ptr;
     dtype = t.data.dtype;
+  } else if (!mx && !t.has_columnwise_data() && t.has_data() && t.last_dims.ptr == nullptr) {
+    // per-tensor FP8 without transposed copies: the row-wise payload is read K-major (ds_read_b64_tr_b8), as the
+    // dense GEMM does; the members share one row length
+    const GroupShapes gs = group_shapes_of(t);
+    NVTE_CHECK(gs.uniform_last > 0 && gs.uniform_last % 16 == 0 && gs.uniform_last < (1ll << 31), "Grouped GEMM: ", name,
+               " has no column-wise data and its last dimension (", gs.uniform_last,
+               ") cannot be read K-major (multiple of 16 needed)");
+    m.base = static_cast<const uint8_t *>(t.data.ptr);
+    sinv = t.scale_inv.ptr;
+    dtype = t.data.dtype;
+    m.k_major = 1;
+    m.ld = static_cast<unsigned>(gs.uniform_last);
   } else {
     NVTE_CHECK(t.has_columnwise_data(), "Grouped GEMM: ", name, " is missing column-wise data needed for TN layout");
     // MXFP8: the contraction runs over the members' stored rows, which the gfx950 MFMA path can only read
@@ -1878,8 +1907,10 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
       const Tensor &t = *lookup_checked(call.a_list[i]);
       NVTE_CHECK(is_tensor_scaling(t.scaling_mode), "Grouped GEMM: A_list tensor ", i,
                  " must use FP8 per-tensor scaling");
-      const Buf &payload = transa ? t.data : t.columnwise_data;
-      const Buf &sinv = transa ? t.scale_inv : t.columnwise_scale_inv;
+      // no transposed copy: the row-wise payload is read K-major (all list members then need one row length)
+      const bool a_km = !transa && t.columnwise_data.ptr == nullptr && t.data.ptr != nullptr;
+      const Buf &payload = (transa || a_km) ? t.data : t.columnwise_data;
+      const Buf &sinv = (transa || a_km) ? t.scale_inv : t.columnwise_scale_inv;
       NVTE_CHECK(payload.ptr != nullptr, "Grouped GEMM: A_list tensor ", i, " is missing ",
                  transa ? "row-wise" : "column-wise", " data");
       NVTE_CHECK(is_fp8(payload.dtype), "Grouped GEMM: A_list tensor ", i, " must be FP8");
@@ -1890,6 +1921,13 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
       NVTE_CHECK(payload.dtype == a_dtype, "Grouped GEMM: A_list tensors must share one dtype");
       const auto dims = t.flat2d();  // logical [first, last]
       NVTE_CHECK(dims[0] < (1ull << 31) && dims[1] < (1ull << 31), "Grouped GEMM: A_list tensor ", i, " too large");
+      NVTE_CHECK(i == 0 || (a_km ? 1 : 0) == A.k_major, "Grouped GEMM: A_list tensors must all carry column-wise data or none");
+      if (a_km) {
+        NVTE_CHECK(dims[1] % 16 == 0 && (i == 0 || A.ld == dims[1]), "Grouped GEMM: A_list tensors without column-wise "
+                   "data are read K-major and need one last dimension, a multiple of 16 (tensor ", i, ": ", dims[1], ")");
+        A.k_major = 1;
+        A.ld = static_cast<unsigned>(dims[1]);
+      }
       la.ptr[i] = static_cast<const uint8_t *>(payload.ptr);
       la.scale_inv[i] = static_cast<const float *>(sinv.ptr);
       la.first[i] = static_cast<unsigned>(dims[0]);
@@ -1972,10 +2010,18 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   g.d_dtype = d_dtype;
   g.grid = cus;  // persistent: the tile count is only known on the device
   (void)api;
-  if (mx)
+  g.ldP = B.ld;
+  g.ldQ = A.ld;
+  if (mx) {
     launch_by_format<true, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
-  else
-    launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
+  } else {
+    switch ((B.k_major ? 1 : 0) | (A.k_major ? 2 : 0)) {
+      case 0: launch_by_format<false, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+      case 1: launch_by_format<false, false, true, 1>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+      case 2: launch_by_format<false, false, true, 2>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+      default: launch_by_format<false, false, true, 3>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+    }
+  }
 }
 
 // ---- nvte_amd_multi_gemm (amd_ext.h): a LIST of independent GEMMs in one persistent launch --------------

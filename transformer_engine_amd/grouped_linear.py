@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 
 from .grouped import (GroupedTensor, general_grouped_gemm_for_grouped_tensor, group_quantize,
@@ -28,9 +30,18 @@ from .tensor import Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantiz
 
 
 class GroupedLinearFP8State:
-    def __init__(self, recipe, num_gemms: int, device=None):
+    def __init__(self, recipe, num_gemms: int, device=None, fp8_transposes: Optional[str] = None):
+        """fp8_transposes (per-tensor FP8 recipes, the grouped-tensor path): "all" = transposed copies of X, W and dY per
+        member, "none" = row-wise payloads only, the grouped dgrad / wgrad read them K-major (as LinearFP8State;
+        default NVTE_AMD_FP8_TRANSPOSES, else linear.FP8_TRANSPOSES_DEFAULT).  MXFP8 members always keep their
+        transposed columnwise copies; the legacy list path keeps all transposes."""
+        from .linear import FP8_TRANSPOSES_DEFAULT
         self.recipe, self.num_gemms = recipe, num_gemms
         self.device = device or torch.device("cuda")
+        mode = fp8_transposes or os.environ.get("NVTE_AMD_FP8_TRANSPOSES") or FP8_TRANSPOSES_DEFAULT
+        if mode not in ("all", "grad_output", "input", "none"):
+            raise ValueError("fp8_transposes must be 'all' or 'none'")
+        self.keep_transposes = mode != "none" or isinstance(recipe, MXFP8BlockScaling)
         f, b = get_fp8_te_dtype(recipe.fp8_format, True), get_fp8_te_dtype(recipe.fp8_format, False)
         if isinstance(recipe, Float8CurrentScaling):
             mk = lambda dt: Float8CurrentScalingQuantizer(dt, self.device, force_pow_2_scales=recipe.use_power_2_scales,
@@ -93,10 +104,10 @@ def grouped_linear_forward(x: torch.Tensor, weight: torch.Tensor, first_dims: to
     G = st.num_gemms
     K = x.shape[-1]
     N = weight.shape[0] // G
-    st.q_input.set_usage(rowwise=True, columnwise=needs_backward)
+    st.q_input.set_usage(rowwise=True, columnwise=needs_backward and st.keep_transposes)
     x8 = group_quantize(x, st.q_input, G, first_dims=first_dims)
     if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
-        st.q_weight.set_usage(rowwise=True, columnwise=needs_backward)
+        st.q_weight.set_usage(rowwise=True, columnwise=needs_backward and st.keep_transposes)
         w8 = group_quantize(weight, st.q_weight, G)
         if is_first_microbatch is not None:
             st.weight_cache = w8
@@ -113,7 +124,7 @@ def grouped_linear_backward(dy: torch.Tensor, saved, first_dims: torch.Tensor, s
     x8, w8, K, N = saved
     G = st.num_gemms
     dy = dy if dy.is_contiguous() else dy.contiguous()
-    st.q_grad.set_usage(rowwise=True, columnwise=True)
+    st.q_grad.set_usage(rowwise=True, columnwise=st.keep_transposes)
     dy8 = group_quantize(dy, st.q_grad, G, first_dims=first_dims)
     dx = _hp_out(first_dims, dy.shape[0], K, G, dy.dtype)
     general_grouped_gemm_for_grouped_tensor(w8, dy8, dx, layout="NN")
