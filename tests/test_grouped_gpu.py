@@ -278,15 +278,29 @@ def test_grouped_gemm_capped_workgroup_count_exact(sm_count):
         r0 += m
 
 
-def test_grouped_gemm_dgrad_wgrad_exact_with_accumulate_and_alpha_beta():
+@pytest.mark.parametrize("operands", ["transposed", "k_major", "k_major_list"])
+def test_grouped_gemm_dgrad_wgrad_exact_with_accumulate_and_alpha_beta(operands):
+    """operands: "transposed" = per-member transposed copies (K-contiguous reads); "k_major" = row-wise payloads only,
+    the kernel reads W (dgrad) and X, dY (wgrad) K-major through ds_read_b64_tr_b8; "k_major_list" = additionally W as
+    a discrete list of tensors without transposes (nvte_grouped_gemm_with_discrete_inputA)."""
     m_splits, N, K = [256, 48, 0, 512], 256, 384
     G = len(m_splits)
     dY, dys = _int_group([(m, N) for m in m_splits], E5, 3, [1.0, 0.5, 2.0, 0.25])
     W, ws = _int_group([(N, K)] * G, E4, 4, [1.0, 2.0, 4.0, 0.5])
     X, xs = _int_group([(m, K) for m in m_splits], E4, 5, [2.0, 1.0, 1.0, 0.5])
+    A_w = W
+    if operands != "transposed":
+        for t in (dY, W, X):
+            t.columnwise_data = None
+            t.columnwise_scale_inv = None
+        if operands == "k_major_list":
+            A_w = [Float8Tensor(shape=(N, K), dtype=torch.float32,
+                                data=torch.from_numpy(oracle.float_to_fp8(ws[i], oracle.E4M3)).cuda(),
+                                fp8_scale_inv=torch.full((1,), [1.0, 2.0, 4.0, 0.5][i], device="cuda"), fp8_dtype=E4,
+                                data_transpose=None) for i in range(G)]
     # dgrad: dX_i [m_i, K] = dY_i W_i   (NN: A = W, B = dY)
     dx = _hp_group([(m, K) for m in m_splits], torch.bfloat16)
-    general_grouped_gemm_for_grouped_tensor(W, dY, dx, layout="NN")
+    general_grouped_gemm_for_grouped_tensor(A_w, dY, dx, layout="NN")
     # wgrad: dW_i [N, K] = dY_i^T X_i   (NT: A = X, B = dY), discrete outputs, beta = per-member accumulate
     base = [torch.full((N, K), float(i + 1), dtype=torch.float32, device="cuda") for i in range(G)]
     outs = [b.clone() for b in base]
