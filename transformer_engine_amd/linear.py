@@ -232,7 +232,12 @@ def layernorm_linear_forward(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: 
     bf16 round trip through HBM.  Returns (y, saved)."""
     from .normalization import layernorm_fwd, rmsnorm_fwd
     qi, qw = st.fwd_q[FWD_INPUT], st.fwd_q[FWD_WEIGHT]
-    qi.set_usage(rowwise=True, columnwise=needs_backward)
+    # per-tensor FP8: the norm kernel writes a transposed copy of its output only where the state keeps one
+    # (fp8_transposes, as linear_forward); the backward GEMMs read the row-wise bytes K-major otherwise
+    per_tensor = not isinstance(qi, MXFP8Quantizer)
+    col_w = needs_backward and not (st.fp8_transposes != "all" and per_tensor)
+    col_x = needs_backward and not (st.fp8_transposes in ("grad_output", "none") and per_tensor)
+    qi.set_usage(rowwise=True, columnwise=col_x)
     if isinstance(qi, MXFP8Quantizer):
         qi.optimize_for_gemm = False       # the norm kernels write compact scales only (ref ln_api.cpp:36)
     x2d = x.reshape(-1, x.shape[-1])
@@ -244,7 +249,7 @@ def layernorm_linear_forward(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: 
     else:
         raise ValueError(f"unsupported normalization {normalization}")
     if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
-        qw.set_usage(rowwise=True, columnwise=needs_backward)
+        qw.set_usage(rowwise=True, columnwise=col_w)
         w8 = qw(weight)
         if is_first_microbatch is not None:
             st.weight_cache = w8
