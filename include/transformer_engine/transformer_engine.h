@@ -150,7 +150,7 @@ enum NVTEQuantizationConfigAttribute {
 /* ref :483.  Returns 0 by default: callers then materialise the pre-transposed
  * ("columnwise") FP8 copy and all three Linear GEMMs reach the MFMA kernel with
  * K-contiguous operands.  Since round 3 the GEMM also reads row-wise payloads of
- * non-TN operands K-major at 96-99 % of that rate: with
+ * non-TN operands K-major at 95-98 % of that rate: with
  * NVTE_AMD_NON_TN_FP8_GEMM=1 in the environment this returns 1 and a framework
  * may skip the transposes (casts at 3 instead of 4 bytes per element). */
 int nvte_is_non_tn_fp8_gemm_supported(void);

@@ -229,11 +229,15 @@ __device__ __forceinline__ v4i_t uniform4(const v4i_t r) {
   return v4i_t{__builtin_amdgcn_readfirstlane(r[0]), __builtin_amdgcn_readfirstlane(r[1]),
                __builtin_amdgcn_readfirstlane(r[2]), __builtin_amdgcn_readfirstlane(r[3])};
 }
+// Wait states inside the string (the compiler pads nothing there): `s_nop 3` separates the write of M0 from the DMA that
+// reads it (1 state needed) and, together with the s_mov, gives the 5 states a VMEM instruction needs after a VALU
+// instruction wrote one of its SGPR operands - which happens right in front of the statement whenever the compiler
+// reloads a spilled SGPR (v_readlane) or makes a descriptor word uniform (v_readfirstlane, the grouped kernels).
 __device__ __forceinline__ void glds_b128(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
   rsrc = uniform4(rsrc);
   lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
   soff = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 // 64 lanes x 4 bytes -> LDS [lds_addr, lds_addr + 256)
@@ -241,7 +245,7 @@ __device__ __forceinline__ void glds_b32(v4i_t rsrc, unsigned lds_addr, unsigned
   rsrc = uniform4(rsrc);
   lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
   soff = __builtin_amdgcn_readfirstlane(soff);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dword %1, %2, %3 offen lds"
                :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 

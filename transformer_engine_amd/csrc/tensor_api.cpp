@@ -669,7 +669,7 @@ void nvte_tensor_pack_destroy(NVTETensorPack *pack) {
   });
 }
 
-// The GEMM reads row-wise FP8 payloads of a non-TN operand K-major (ds_read_b64_tr_b8) at 96-99 % of the K-contiguous
+// The GEMM reads row-wise FP8 payloads of a non-TN operand K-major (ds_read_b64_tr_b8) at 95-98 % of the K-contiguous
 // rate, so a framework may skip the transposed copies: NVTE_AMD_NON_TN_FP8_GEMM=1 makes this query say so (the reference's
 // Float8Quantizer then allocates no transpose, csrc/quantizer.cpp:342-356).  The default stays 0, the answer every caller
 // of rounds 1-2 was built against; this package's own Linear states skip the transposes either way

@@ -68,7 +68,7 @@ def bgrad_quantize(dy: torch.Tensor, quantizer):
 # DESIGN 6c); both run through the same GEMM entry point
 MX_COLUMNWISE_DEFAULT = "reference"
 # which per-tensor FP8 tensors of a Linear keep a transposed copy for the backward GEMMs: "none" - the GEMM reads
-# row-wise payloads K-major at 96-99 % of the K-contiguous rate, the casts move 3 instead of 4 bytes per element and
+# row-wise payloads K-major at 95-98 % of the K-contiguous rate, the casts move 3 instead of 4 bytes per element and
 # the configs[1] step is 7 % faster; "all" is the reference's data flow on hardware without non-TN FP8
 # GEMMs.  Outputs and recipe state are bit-equal either way.
 FP8_TRANSPOSES_DEFAULT = "none"
