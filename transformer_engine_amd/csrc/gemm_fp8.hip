@@ -240,6 +240,29 @@ __device__ __forceinline__ void glds_b128(v4i_t rsrc, unsigned lds_addr, unsigne
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// Two DMAs in one statement (the P and the Q piece of one staging step): the second one's scalar operands are more than
+// 5 states past anything in front of the statement, so it only needs the one state behind its own write of M0.
+// BARE: no padding for a VALU-written SGPR operand - only where the generated code is KNOWN to hold no VALU instruction
+// that writes an SGPR (v_readlane / v_readfirstlane / v_cmp to an SGPR pair) anywhere near: the steady-state K loop of
+// the dense per-tensor kernels, checked at every build of the test suite by tests/test_gemm_codegen.py.
+template <bool BARE>
+__device__ __forceinline__ void glds_b128_pair(v4i_t r0, unsigned lds0, unsigned voff0, unsigned soff0,
+                                               v4i_t r1, unsigned lds1, unsigned voff1, unsigned soff1) {
+  r0 = uniform4(r0);
+  r1 = uniform4(r1);
+  lds0 = __builtin_amdgcn_readfirstlane(lds0);
+  lds1 = __builtin_amdgcn_readfirstlane(lds1);
+  soff0 = __builtin_amdgcn_readfirstlane(soff0);
+  soff1 = __builtin_amdgcn_readfirstlane(soff1);
+  if constexpr (BARE)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, %7 offen lds"
+                 :: "s"(lds0), "v"(voff0), "s"(r0), "s"(soff0), "s"(lds1), "v"(voff1), "s"(r1), "s"(soff1) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, %7 offen lds"
+                 :: "s"(lds0), "v"(voff0), "s"(r0), "s"(soff0), "s"(lds1), "v"(voff1), "s"(r1), "s"(soff1) : "memory");
+}
 // 64 lanes x 4 bytes -> LDS [lds_addr, lds_addr + 256)
 __device__ __forceinline__ void glds_b32(v4i_t rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
   rsrc = uniform4(rsrc);
@@ -548,9 +571,21 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
         glds_b128(rq, la, voff[q & 1], soff);
     }
   };
-  auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2]) {
-    stage_P(t, slot, k0, q, voff);
-    stage_Q(t, slot, k0, q, voff);
+  auto stage_rows = [&](const TileCtx &t, unsigned slot, unsigned k0, int q, const unsigned(&voff)[2], auto hot_tag) {
+    // hot = called from the steady-state K loop (not the prologue, not the two K tiles peeled off at a tile boundary)
+    constexpr bool BARE = decltype(hot_tag)::value && !MX && !GROUPED;
+    if constexpr (kAsmDma) {
+      uint8_t *base = lds + slot * kStageBytes;
+      const unsigned soff = (wave * 4 + q) * 8 * (GROUPED ? t.k : a.k) + k0;
+      const unsigned la_p = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_u8 *)(base + (wave * 4 + q) * 1024)));
+      const unsigned la_q = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_u8 *)(base + BM * BK + (wave * 4 + q) * 1024)));
+      const unsigned kmo = (k0 + (wave * 4 + q) * 4);
+      glds_b128_pair<BARE>(make_rsrc(t.pbase, t.pbytes), la_p, PKM ? km_voffP + (q & 1) * km_flip : voff[q & 1], PKM ? kmo * a.ldP : soff,
+                     make_rsrc(t.qbase, t.qbytes), la_q, QKM ? km_voffQ + (q & 1) * km_flip : voff[q & 1], QKM ? kmo * a.ldQ : soff);
+    } else {
+      stage_P(t, slot, k0, q, voff);
+      stage_Q(t, slot, k0, q, voff);
+    }
   };
   auto stage_voff = [&](const TileCtx &t, unsigned k0, unsigned(&voff)[2]) {
 #pragma unroll
@@ -565,7 +600,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     unsigned voff[2];
     stage_voff(t, k0, voff);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) stage_rows(t, slot, k0, q, voff);
+    for (int q = 0; q < 4; ++q) stage_rows(t, slot, k0, q, voff, std::false_type{});
   };
 
   // Fragment read geometry.  A lane needs chunks c = half + 2q (q = 0..3) of its row; with the
@@ -761,7 +796,7 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // K tile two ahead (`st` / `st_k0`: which output tile and which K offset that is) + the MX
   // scale hand-over.  `g` counts K tiles across output tiles and picks the LDS slot.
   auto k_tile = [&](unsigned g, const TileCtx &st, unsigned st_k0, unsigned st_kt, unsigned commit_kt,
-                    unsigned commit_k, auto prefetch_tag) {
+                    unsigned commit_k, auto prefetch_tag, auto hot_tag) {
     constexpr bool PREFETCH = decltype(prefetch_tag)::value;  // fetch the next K tile's first fragments
     const unsigned cur = g & 1u, nxt = cur ^ 1u;
     mm(I0{}, I0{}, I0{}, p[0], q[0][0]);
@@ -814,15 +849,15 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     if constexpr (PREFETCH) rdQ(nxt, 0, 0, q[0][0]);
     mm(I1{}, I1{}, I0{}, p[1], q[1][0]);
     if constexpr (PREFETCH) rdQ(nxt, 0, 1, q[0][1]);
-    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 0, voff);
+    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 0, voff, hot_tag);
     mm(I1{}, I1{}, I1{}, p[1], q[1][1]);
     if constexpr (PREFETCH) rdP(nxt, 0, 1, p[1]);
-    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 1, voff);
+    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 1, voff, hot_tag);
     mm(I1{}, I2{}, I0{}, p[2], q[1][0]);
-    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 2, voff);
+    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 2, voff, hot_tag);
     mm(I1{}, I2{}, I1{}, p[2], q[1][1]);
     if constexpr (PREFETCH) rdP(nxt, 0, 2, p[2]);
-    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 3, voff);
+    if constexpr (!(ABL & 1)) stage_rows(st, cur, st_k0, 3, voff, hot_tag);
     stage_scales(st, cur, st_kt);
     mm(I1{}, I3{}, I0{}, p[3], q[1][0]);
     mm(I1{}, I3{}, I1{}, p[3], q[1][1]);
@@ -1083,13 +1118,13 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
     const unsigned nk_t = GROUPED ? max((cur_t.k + BK - 1) / BK, 2u) : nk;
     const unsigned k_cur = GROUPED ? cur_t.k : a.k, k_next = GROUPED ? next_t.k : a.k;
     for (unsigned kt = 0; kt + 2 < nk_t; ++kt, ++g)
-      k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, k_cur, std::true_type{});
+      k_tile(g, cur_t, (kt + 2) * BK, kt + 2, kt + 1, k_cur, std::true_type{}, std::true_type{});
     if (nk_t >= 2) {
-      k_tile(g, next_t, 0, 0, nk_t - 1, k_cur, std::true_type{});
+      k_tile(g, next_t, 0, 0, nk_t - 1, k_cur, std::true_type{}, std::false_type{});
       ++g;
     }
     // the last K tile leaves the fragment registers dead, so the epilogue has room to work in
-    k_tile(g, next_t, BK, 1, 0, k_next, std::false_type{});
+    k_tile(g, next_t, BK, 1, 0, k_next, std::false_type{}, std::false_type{});
     ++g;
     TE_STAMP();
 #ifdef TE_GEMM_STAMPS
