@@ -536,11 +536,12 @@ class ColumnParallelLinearSP:
         else:
             dx_partial, *_ = general_gemm(w8, dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
             dx_local, handle = reduce_scatter_along_first_dim(dx_partial, self.group, async_op=True)
-        # wgrad needs X^T of the GATHERED input: rebuilt locally (ref distributed.py:1067-1075)
+        # wgrad contracts over the rows of the GATHERED input.  The reference rebuilds X^T locally after the gather
+        # (distributed.py:1067-1075); here only the K-chunked pipeline does (its chunks are column slices, whose
+        # transposes are the row blocks of X^T) - a gathered row-wise tensor is read K-major by the GEMM as it is
+        # (ds_read_b64_tr_b8, DESIGN 3.6c: bit-equal, one pass over the gathered bytes fewer)
         if isinstance(x8, _GatheredChunks):
             x8 = x8.as_transposed_tensor()
-        elif isinstance(x8, Float8Tensor) and (x8._transpose is None or x8._transpose_invalid):
-            x8._create_transpose()
         dw, *_ = general_gemm(x8, dy8, out_dtype=self.out_dtype, layout="NT", grad=True)
         if handle is not None:
             handle.wait()
@@ -720,8 +721,10 @@ class RowParallelLinearSP:
         x8, w8 = saved
         st = self.state
         qg = st.bwd_q[BWD_GRAD_OUTPUT]
+        # ref base.py:1680-1684 gathers dY and rebuilds its transpose for wgrad; per-tensor FP8: wgrad reads the gathered
+        # row-wise bytes K-major instead (no transpose pass over [M_total, N]); MXFP8 gathers its columnwise pair
         dy8 = gather_along_first_dim(dy_local.reshape(-1, dy_local.shape[-1]), self.group, quantizer=qg,
-                                     need_transpose=True)      # ref base.py:1680-1684
+                                     need_transpose=False)
         dx, *_ = general_gemm(w8, dy8, out_dtype=self.out_dtype, layout="NN", grad=True)
         dw, *_ = general_gemm(x8, dy8, out_dtype=self.out_dtype, layout="NT", grad=True)
         st.update_bwd(self.group)
