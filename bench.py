@@ -729,9 +729,9 @@ def main():
                 "recipe_kernel_and_launch_gaps_ms": ms_per_step - hot_net_ms,
                 "recipe_kernel_and_launch_gaps_share": (ms_per_step - hot_net_ms) / ms_per_step,
                 "note": "hot kernels timed in eager instrumented steps (HIP event pairs, MEDIAN launch, the measured empty-pair "
-                        "floor subtracted once per kernel), ms_per_step from the hipGraph replay: the remainder is the ONE "
+                        "floor subtracted once per kernel), ms_per_step from the timed region (config.timed_as): the remainder is the ONE "
                         "recipe-update kernel of the step (forward + backward states in one launch; amax rows are "
-                        "zeroed by that kernel, there is no memset) and the graph's five inter-kernel gaps"},
+                        "zeroed by that kernel, there is no memset) and the five inter-kernel gaps"},
             "in_step_ms": step_ms,
             "in_step_ms_with_all_transposes": ct_step_ms,
             "isolated_note": "gemm_ms / cast_transpose_ms below: the same kernel launched back to back on resident "
