@@ -387,3 +387,47 @@ def test_linear_without_input_and_weight_transposes_equals_default(mode):
         for a, b in zip(outs[0][:3], outs[1][:3]):
             assert torch.equal(a, b), it
         assert torch.equal(sa.fwd_state.scale, sb.fwd_state.scale) and torch.equal(sa.bwd_state.scale, sb.bwd_state.scale)
+
+
+def test_non_tn_answer_makes_the_quantizers_skip_transposes_subprocess():
+    """NVTE_AMD_NON_TN_FP8_GEMM=1: nvte_is_non_tn_fp8_gemm_supported() says 1 and, as in the reference on hardware with
+    non-TN FP8 GEMMs (csrc/quantizer.cpp:342-356), the per-tensor quantizers allocate no transposed copy even for
+    column-wise usage; a Linear step that ASKS for all transposes then runs dgrad / wgrad on K-major reads of the
+    row-wise bytes.  Own process (the library reads the variable once); y against the FP32 matmul of the dequantized
+    operands (bf16 output rounding 2^-8 relative + 2e-3 of the absmax), dx / dw loosely (see below)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys; sys.path.insert(0, %r)
+import torch
+from transformer_engine_amd import _lib, linear as L
+from transformer_engine_amd.recipe import DelayedScaling
+assert _lib.api.nvte_is_non_tn_fp8_gemm_supported() == 1
+g = torch.Generator().manual_seed(3)
+M, K, N = 512, 384, 640
+x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+dy = (torch.randn(M, N, generator=g) * 0.01).to(torch.bfloat16).cuda()
+st = L.LinearFP8State(DelayedScaling(amax_history_len=4), device=torch.device("cuda"), fp8_transposes="all")
+for it in range(3):
+    y, saved = L.linear_forward(x, w, None, st, is_first_microbatch=True)
+    dx, dw, _ = L.linear_backward(dy, saved, st)
+    st.update_fwd_bwd()
+x8, w8 = saved
+assert x8._transpose is None and w8._transpose is None and x8._data is not None
+xf, wf = x8.dequantize().float(), w8.dequantize().float()
+def close(a, b, tol):
+    a, b = a.float(), b.float()
+    assert torch.allclose(a, b, rtol=2 ** -7, atol=tol * b.abs().max().item()), (a - b).abs().max().item()
+close(y, xf @ wf.t(), 2e-3)
+# dY is quantized to E5M2 inside linear_backward (2 mantissa bits): that rounding is part of the difference to these
+# references, hence the wide tolerance - the K-major arithmetic itself is pinned exactly by the tests above
+close(dx, dy.float() @ wf, 0.15)
+close(dw, dy.float().t() @ xf, 0.15)
+print("OK")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, NVTE_AMD_NON_TN_FP8_GEMM="1"),
+                         capture_output=True, text=True, timeout=300)
+    assert out.stdout.strip().endswith("OK"), (out.stdout[-2000:], out.stderr[-2000:])

@@ -314,8 +314,10 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   // waits cost more than its extra scalar instructions do - both operands K-major (wgrad: 463 -> 371 us per-tensor, 511 ->
   // 442 us MXFP8 at the configs[1] / 8192^3 shapes) and the per-tensor dgrad (346 -> 336 us); the builtin form where
   // they do not (K-contiguous operands: 2 % faster with the builtin; MXFP8 with only Q K-major: 3 %).
-#ifdef TE_GEMM_BUILTIN_DMA
+#if defined(TE_GEMM_BUILTIN_DMA)
   constexpr bool kAsmDma = false;
+#elif defined(TE_GEMM_ASM_DMA_ALL)   // A/B builds: the assembly form in every dense kernel
+  constexpr bool kAsmDma = !GROUPED;
 #else
   constexpr bool kAsmDma = PKM || (!MX && QKM);
 #endif

@@ -458,10 +458,12 @@ class Float8Quantizer(Quantizer):
     def make_empty(self, shape, *, dtype=torch.float32, device=None) -> Float8Tensor:
         device = device or torch.device("cuda")
         rows, cols = _flat2d(tuple(shape))
-        data = torch.empty(tuple(shape), dtype=torch.uint8, device=device) if self.rowwise_usage else None
-        # nvte_is_non_tn_fp8_gemm_supported() == 0 -> the transposed copy is materialised
-        # (ref csrc/quantizer.cpp:342-356)
-        tr = torch.empty((cols, rows), dtype=torch.uint8, device=device) if self.columnwise_usage else None
+        # ref csrc/quantizer.cpp:342-356: where non-TN FP8 GEMMs are supported the row-wise payload serves both
+        # usages and no transposed copy is allocated (here: NVTE_AMD_NON_TN_FP8_GEMM=1, the GEMM reads it K-major);
+        # otherwise - the default answer of the library - column-wise usage materialises the transpose
+        non_tn = non_tn_fp8_gemm_supported()
+        data = torch.empty(tuple(shape), dtype=torch.uint8, device=device) if (self.rowwise_usage or non_tn) else None
+        tr = torch.empty((cols, rows), dtype=torch.uint8, device=device) if (self.columnwise_usage and not non_tn) else None
         sinv = torch.empty(1, dtype=torch.float32, device=device)
         return Float8Tensor(shape=shape, dtype=dtype, data=data, fp8_scale_inv=sinv,
                             fp8_dtype=self.dtype, data_transpose=tr, quantizer=self)
