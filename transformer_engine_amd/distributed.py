@@ -392,9 +392,14 @@ class ColumnParallelLinearSP:
     token shard while wgrad runs; amax all-reduce (MAX) once per fwd and once per bwd."""
 
     def __init__(self, in_features: int, out_features: int, tp: int, rank: int, recipe=None,
-                 device=None, group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2):
+                 device=None, group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2,
+                 activation_transposes: bool = False):
         from .linear import FWD_INPUT, LinearFP8State
         assert out_features % tp == 0
+        # per-tensor FP8: dY is cast row-wise only (3 B/element) and wgrad reads it K-major (DESIGN 3.6c, bit-equal);
+        # True restores the cast_transpose of rounds 1-2.  The cached weight keeps its transpose (dgrad's output-column
+        # pieces are row blocks of it).  MXFP8 always carries its columnwise pair.
+        self.activation_transposes = activation_transposes
         self.K, self.N_local, self.tp, self.rank, self.group = in_features, out_features // tp, tp, rank, group
         self.device = device or torch.device("cuda")
         g = torch.Generator(device="cpu").manual_seed(4321 + rank)
@@ -520,7 +525,7 @@ class ColumnParallelLinearSP:
         x8, w8 = saved
         st = self.state
         qg = st.bwd_q[BWD_GRAD_OUTPUT]
-        qg.set_usage(rowwise=True, columnwise=True)
+        qg.set_usage(rowwise=True, columnwise=isinstance(qg, MXFP8Quantizer) or self.activation_transposes)
         dy8 = qg(dy)
         # dgrad partial sums [M_total, K] -> reduce-scatter to this rank's tokens, asynchronously.  With the overlap on,
         # dgrad is cut along its OUTPUT columns (row blocks of the K-contiguous W^T copy: views, no copy): piece j's
@@ -595,8 +600,9 @@ class ColumnParallelLayerNormLinearSP(ColumnParallelLinearSP):
     def __init__(self, in_features: int, out_features: int, tp: int, rank: int, recipe=None, device=None,
                  group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2,
                  normalization: str = "RMSNorm", eps: float = 1e-5, zero_centered_gamma: bool = False,
-                 allreduce_norm_grads: bool = False):
-        super().__init__(in_features, out_features, tp, rank, recipe, device, group, params_dtype, overlap, chunks)
+                 allreduce_norm_grads: bool = False, activation_transposes: bool = False):
+        super().__init__(in_features, out_features, tp, rank, recipe, device, group, params_dtype, overlap, chunks,
+                         activation_transposes)
         if normalization not in ("LayerNorm", "RMSNorm"):
             raise ValueError(f"unsupported normalization {normalization}")
         self.normalization, self.eps, self.zero_centered_gamma = normalization, eps, zero_centered_gamma
@@ -673,9 +679,12 @@ class RowParallelLinearSP:
     dgrad and wgrad run on the full token set without further communication."""
 
     def __init__(self, in_features: int, out_features: int, tp: int, rank: int, recipe=None, device=None,
-                 group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2):
+                 group=None, params_dtype=torch.bfloat16, overlap: bool = True, chunks: int = 2,
+                 activation_transposes: bool = False):
         from .linear import BWD_GRAD_OUTPUT, LinearFP8State
         assert in_features % tp == 0
+        # per-tensor FP8: X is cast row-wise only and wgrad reads X and the gathered dY K-major (see the column layer)
+        self.activation_transposes = activation_transposes
         self.K_local, self.N, self.tp, self.rank, self.group = in_features // tp, out_features, tp, rank, group
         self.device = device or torch.device("cuda")
         g = torch.Generator(device="cpu").manual_seed(8765 + rank)
@@ -696,7 +705,7 @@ class RowParallelLinearSP:
             qw.set_usage(rowwise=True, columnwise=True)
             st.weight_cache = qw(self.weight)
         w8 = st.weight_cache
-        qi.set_usage(rowwise=True, columnwise=True)
+        qi.set_usage(rowwise=True, columnwise=isinstance(qi, MXFP8Quantizer) or self.activation_transposes)
         x8 = qi(x)
         M = x.shape[0]
         if self.overlap and collectives_active(self.group):
