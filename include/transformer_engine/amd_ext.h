@@ -47,18 +47,17 @@ void nvte_amd_delayed_scaling_after_reduction_multi(const NVTETensor amax_reduct
                                                     size_t num_tensors, const char *amax_compute_algo,
                                                     float margin, hipStream_t stream);
 
-/* MXFP8 "transposed columnwise" layout (no counterpart in the reference).
+/* MXFP8 "transposed columnwise" layout (no counterpart in the reference; OPTIONAL since round 3).
  * The reference keeps the columnwise-quantized MXFP8 payload in the input's own [rows, cols]
- * layout and lets cuBLASLt read it as a non-TN operand.  gfx950's MFMA needs K-contiguous
- * operands, so -- exactly as nvte_is_non_tn_fp8_gemm_supported() == 0 makes per-tensor FP8 callers
- * keep a transposed copy -- an MXFP8 output tensor can ask nvte_quantize* to store its
- * columnwise payload transposed:
+ * layout and lets cuBLASLt read it as a non-TN operand; nvte_cublas_gemm* here read that layout
+ * K-major through the transposing LDS loads (the default, nothing to set).  An MXFP8 output tensor
+ * can instead ask nvte_quantize* to store its columnwise payload transposed (K-contiguous):
  *   columnwise_data       [cols, rows]              (FP8 bytes, blocks of 32 along the LAST dim)
  *   columnwise_scale_inv  [pad128(cols), pad4(ceil(rows/32))]   (e8m0; GEMM-swizzled if the
  *                          tensor's with_gemm_swizzled_scales flag is set -- for that flag the
  *                          bytes are identical to the reference's swizzled columnwise scales)
- * nvte_cublas_gemm* consume such tensors for the NN / NT layouts (dgrad / wgrad); without the
- * flag those MXFP8 layouts are rejected.  Default 0 = reference layout. */
+ * nvte_cublas_gemm* consume either layout for the NN / NT layouts (dgrad / wgrad).  Default 0 =
+ * reference layout. */
 void nvte_amd_set_columnwise_transposed(NVTETensor tensor, int transposed);
 int nvte_amd_get_columnwise_transposed(const NVTETensor tensor);
 
@@ -66,8 +65,9 @@ int nvte_amd_get_columnwise_transposed(const NVTETensor tensor);
  * member's payload transposed ([last, first_i] at the member's element offset) and
  * columnwise_scale_inv the members' [pad128(last), pad4(first_i / 32)] scale matrices back to back
  * (member i at the sum of the padded sizes before it - the offset rule of ref
- * gemm/cublaslt_grouped_gemm.cu:1117-1198).  nvte_group_quantize writes this layout when the flag is set
- * and nvte_grouped_gemm* needs it for the NN / NT layouts (dgrad / wgrad).  Member first dims must be
+ * gemm/cublaslt_grouped_gemm.cu:1117-1198).  nvte_group_quantize writes this layout when the flag is set;
+ * nvte_grouped_gemm* takes it or the reference's un-transposed columnwise members (read K-major, members
+ * with one last dimension) for the NN / NT layouts (dgrad / wgrad).  Member first dims must be
  * multiples of 128 for grouped MXFP8 tensors (the reference states the same for the logical first dim,
  * cast/mxfp8/group_quantize_mxfp8.cuh:842, and its swizzled-scale offsets assume it per member). */
 void nvte_amd_set_grouped_columnwise_transposed(NVTEGroupedTensor tensor, int transposed);

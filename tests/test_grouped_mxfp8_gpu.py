@@ -91,6 +91,11 @@ def test_group_quantize_mxfp8_bit_exact(splits, swizzled, fmt, ofmt):
                 if not swizzled:
                     sc = sc_col_flat.reshape(-1, K)[r0 // 32:(r0 + m) // 32]
                     assert np.array_equal(sc, ref["sc_col"][: m // 32, :K])
+                else:
+                    # GEMM-swizzled: a matrix per member, [pad128(K), m / 32] swizzled, behind those of the members
+                    # before it (ref group_quantize_mxfp8.cuh:114-126) - the bytes of the transposed layout's scales
+                    sc = _unswizzle_rows(sc_col_flat[K * (r0 // 32): K * ((r0 + m) // 32)], K, m // 32)
+                    assert np.array_equal(sc, ref["sc_col"][: m // 32, :K].T)
             r0 += m
 
 
@@ -150,13 +155,17 @@ def _hp(fd, rows, cols, G, dtype=torch.float32):
 
 @pytest.mark.parametrize("swizzled", [False, True])
 @pytest.mark.parametrize("splits", [[256, 128, 384, 256], [128, 0, 512, 0]])
-def test_grouped_gemm_mxfp8_fprop_dgrad_wgrad(splits, swizzled):
+@pytest.mark.parametrize("col_layout", ["transposed", "reference"])
+def test_grouped_gemm_mxfp8_fprop_dgrad_wgrad(splits, swizzled, col_layout):
+    """col_layout "reference": the members' columnwise copies keep the members' own shape, the layout the reference's
+    grouped quantize writes (ref cublaslt_grouped_gemm.cu:551-565 hands them to cuBLASLt as non-TN operands); the
+    grouped kernel reads them K-major (ds_read_b64_tr_b8).  "transposed": the amd_ext.h extension."""
     K, N = 512, 384
     G, x, w, dy, fd = _grouped_case(splits, K, N, 11)
     M = x.shape[0]
 
     def mk(dt):
-        q = MXFP8Quantizer(dt, rowwise=True, columnwise=True, columnwise_transposed=True)
+        q = MXFP8Quantizer(dt, rowwise=True, columnwise=True, columnwise_transposed=col_layout == "transposed")
         q.optimize_for_gemm = swizzled
         return q
 
@@ -240,13 +249,37 @@ def test_grouped_gemm_mxfp8_member_off_the_128_contract_is_loud():
             r0 += m
 
 
-def test_grouped_gemm_mxfp8_needs_transposed_columnwise():
-    splits, K, N = [128, 128], 256, 256
+@pytest.mark.parametrize("swizzled", [False, True])
+def test_grouped_gemm_mxfp8_reference_columnwise_layout_equals_transposed(swizzled):
+    """(Round 2 refused the reference's columnwise layout here.)  dgrad and wgrad on members in the reference layout
+    are bit-equal to the same GEMMs on the transposed copies: same tiles, same K order.  Ragged members, an empty
+    one, tiles past the member's rows (N = 384 is 1.5 tiles)."""
+    splits, K, N = [384, 0, 128, 640], 768, 384
     G, x, w, dy, fd = _grouped_case(splits, K, N, 31)
-    w8 = group_quantize(w, MXFP8Quantizer(E4), G)                    # reference columnwise layout
-    dy8 = group_quantize(dy, MXFP8Quantizer(E5), G, first_dims=fd)
-    with pytest.raises(NVTEError, match="transposed columnwise"):
-        general_grouped_gemm_for_grouped_tensor(w8, dy8, _hp(fd, 256, K, G), layout="NN")
+    M = x.shape[0]
+    outs = {}
+    for tcol in (True, False):
+        def mk(dt):
+            q = MXFP8Quantizer(dt, rowwise=True, columnwise=True, columnwise_transposed=tcol)
+            q.optimize_for_gemm = swizzled
+            return q
+        x8 = group_quantize(x, mk(E4), G, first_dims=fd)
+        w8 = group_quantize(w, mk(E4), G)
+        dy8 = group_quantize(dy, mk(E5), G, first_dims=fd)
+        dx = _hp(fd, M, K, G)
+        general_grouped_gemm_for_grouped_tensor(w8, dy8, dx, layout="NN")
+        dws = [torch.full((N, K), float("nan"), dtype=torch.float32, device="cuda") for _ in range(G)]
+        general_grouped_gemm_for_grouped_tensor(x8, dy8, dws, layout="NT")
+        torch.cuda.synchronize()
+        outs[tcol] = (dx.rowwise_data.clone(), [d.clone() for d in dws], x8, dy8)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert not torch.isnan(outs[False][0]).any()
+    for a, b in zip(outs[True][1], outs[False][1]):
+        assert torch.equal(a, b)
+    # what the K-major path does not take is refused loudly: one operand in each layout for wgrad
+    with pytest.raises(NVTEError, match="columnwise layout"):
+        general_grouped_gemm_for_grouped_tensor(outs[True][2], outs[False][3],
+                                                [torch.empty(N, K, device="cuda") for _ in range(G)], layout="NT")
 
 
 def test_group_quantize_mxfp8_rejects_unaligned_shapes():
@@ -255,16 +288,17 @@ def test_group_quantize_mxfp8_rejects_unaligned_shapes():
         group_quantize(x, MXFP8Quantizer(E4), 2)
 
 
-def test_grouped_linear_mxfp8_fwd_bwd_matches_per_member_linear():
+@pytest.mark.parametrize("mx_columnwise", ["reference", "transposed"])
+def test_grouped_linear_mxfp8_fwd_bwd_matches_per_member_linear(mx_columnwise):
     """GroupedLinear with the MXFP8 recipe against the un-grouped MXFP8 Linear per expert (the same
-    kernels member by member: bit-exact)."""
+    kernels member by member: bit-exact), in both columnwise layouts."""
     from transformer_engine_amd import linear as L
     from transformer_engine_amd.grouped_linear import (GroupedLinearFP8State, grouped_linear_backward,
                                                        grouped_linear_forward)
     from transformer_engine_amd.recipe import MXFP8BlockScaling
     splits, K, N = [256, 384, 128], 512, 256
     G, x, w, dy, fd = _grouped_case(splits, K, N, 41)
-    st = GroupedLinearFP8State(MXFP8BlockScaling(), G, torch.device("cuda"))
+    st = GroupedLinearFP8State(MXFP8BlockScaling(), G, torch.device("cuda"), mx_columnwise=mx_columnwise)
     y, saved = grouped_linear_forward(x, w, fd, st)
     dx, dws = grouped_linear_backward(dy, saved, fd, st)
     torch.cuda.synchronize()
@@ -297,7 +331,7 @@ def test_swizzle_grouped_scaling_factors_round_trip(tcol):
         return q
 
     compact = group_quantize(w, mk(False), G)
-    direct = group_quantize(w, mk(True), G) if tcol else None     # (grouped quantize emits swizzled col scales for tcol only)
+    direct = group_quantize(w, mk(True), G)
     swz = copy.copy(compact)
     swz.scale_inv = torch.zeros_like(compact.scale_inv)
     swz.columnwise_scale_inv = torch.zeros_like(compact.columnwise_scale_inv)
@@ -315,10 +349,9 @@ def test_swizzle_grouped_scaling_factors_round_trip(tcol):
     assert torch.equal(back.scale_inv, compact.scale_inv)
     assert torch.equal(back.columnwise_scale_inv, compact.columnwise_scale_inv)
     assert not torch.equal(swz.scale_inv, compact.scale_inv)
-    if direct is not None:
-        assert torch.equal(swz.scale_inv, direct.scale_inv)
-        assert torch.equal(swz.columnwise_scale_inv, direct.columnwise_scale_inv)
-    else:
+    assert torch.equal(swz.scale_inv, direct.scale_inv)
+    assert torch.equal(swz.columnwise_scale_inv, direct.columnwise_scale_inv)
+    if not tcol:
         # reference column-wise layout: member i against the oracle's swizzle of its [N/32, K] scale matrix
         sc = _u8(compact.columnwise_scale_inv).reshape(G, N // 32, K)
         got = _u8(swz.columnwise_scale_inv).reshape(G, -1)

@@ -303,7 +303,7 @@ template <int FA /*format of P: 0 e4m3, 1 e5m2*/, int FB /*format of Q*/, bool M
           int KM = 0>
 __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   static_assert(!(GROUPED && EPI), "the grouped variant has no extended epilogues");
-  static_assert(KM == 0 || (!EPI && !(GROUPED && MX)), "K-major operands: basic epilogue; grouped launches per-tensor FP8 only");
+  static_assert(KM == 0 || !EPI, "K-major operands: basic epilogue only");
   static_assert(MX || (KM & 12) == 0, "scale-layout bits belong to the MXFP8 variants");
   // bits 2 / 3: that K-major operand's e8m0 scales are COMPACT, i.e. stored [k block][row] like the payload (the
   // reference's columnwise scale matrix); otherwise GEMM-swizzled, one format whatever the quantization direction.
@@ -458,6 +458,8 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
         const unsigned tile_row0 = wave < 4 ? t.i0 : t.j0;
         t.ss = e_swz ? ((tile_row0 / 128 + ((wave & 3u) >> 1)) * (stride / 4)) * 512 + (wave & 1u) * 256
                      : (tile_row0 + (wave & 3u) * 64) * stride;
+        // compact scales of a K-major member, [k block][row] (see the dense branch below)
+        if (wave < 4 ? PKC : QKC) t.ss = tile_row0 + (wave & 3u) * stride;
       }
       return t;
     }
@@ -719,20 +721,20 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   //   compact K-major  : wave w of the group = scale row w of the K tile, lane = 4 tile rows, source
   //                      (4 kt + w) * stride + tile row 0 + 4 lane             -> LDS image [k block][256 rows]
   const bool e_kc = wave < 4 ? PKC : QKC;
-  const unsigned e_step = e_swz ? 512u : (e_kc ? 4u * e_stride : 4u);
   auto stage_scales = [&](const TileCtx &t, unsigned slot, unsigned kt) {
     if constexpr (MX) {
       lds_u8 *dst = (lds_u8 *)(lds + kScaleBase + slot * kScaleSlotBytes + wave * 256);
+      const unsigned stride = GROUPED ? t.estride : e_stride;       // (the member's own in a grouped launch)
+      const unsigned e_step = e_swz ? 512u : (e_kc ? 4u * stride : 4u);
+      const unsigned lane_off = GROUPED ? ((e_swz || e_kc) ? lane * 4 : lane * stride) : sv;
       if constexpr (!kAsmDma) {
         const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint8_t *>(GROUPED ? t.eb : e_base), 0, GROUPED ? t.ebytes : e_bytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4,
-                                                 GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(re, (__attribute__((address_space(3))) void *)dst, 4, lane_off,
                                                  t.ss + kt * e_step, 0, 0);
       } else {
         glds_b32(make_rsrc(GROUPED ? t.eb : e_base, GROUPED ? t.ebytes : e_bytes),
-                 static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst)),
-                 GROUPED ? (e_swz ? lane * 4 : lane * t.estride) : sv, t.ss + kt * e_step);
+                 static_cast<unsigned>(reinterpret_cast<uintptr_t>(dst)), lane_off, t.ss + kt * e_step);
       }
     }
   };
@@ -1168,7 +1170,8 @@ __global__ __launch_bounds__(kThreads) void gemm_fp8_kernel(const GemmArgs a) {
   X(false, false, true, 1) X(false, false, true, 2) X(false, false, true, 3)                        \
   X(false, false, false, 1) X(false, false, false, 2) X(false, false, false, 3)                     \
   X(true, false, false, 2) X(true, false, false, 10) X(true, false, false, 3) X(true, false, false, 7) \
-  X(true, false, false, 11) X(true, false, false, 15)
+  X(true, false, false, 11) X(true, false, false, 15)                                              \
+  X(true, false, true, 2) X(true, false, true, 10) X(true, false, true, 3) X(true, false, true, 15)
 #endif
 constexpr int variant_key(bool mx, bool epi, bool grouped, int km) {
   return (mx ? 1 : 0) | (epi ? 2 : 0) | (grouped ? 4 : 0) | (km << 3);
@@ -1605,8 +1608,10 @@ struct GroupedOperandMeta {
   const float *scale_inv = nullptr;  // per-tensor scaling: one entry per member
   const uint8_t *e8m0 = nullptr;     // MXFP8: the members' scale matrices back to back
   int k_is_last = 1;                 // MXFP8: 1 = rowwise storage, 0 = per-member transposed columnwise
-  int k_major = 0;                   // per-tensor FP8: the row-wise payload of an operand contracted over its rows
+  int k_major = 0;                   // the payload of an operand contracted over its ROWS is read as it is stored: per-tensor
+                                     // FP8 row-wise data, MXFP8 the reference's un-transposed columnwise data
   unsigned ld = 0;                   // ... and its row length (bytes between consecutive k), one for all members
+  int km_compact = 0;                // MXFP8 K-major: compact scales, stored [k block][row] per member
   GroupShapes shapes;
 };
 struct GroupedOutMeta {
@@ -1738,6 +1743,8 @@ __global__ __launch_bounds__(64) void grouped_setup_kernel(GroupDesc *descs, uns
     const int64_t rows = o.k_is_last ? first : last, kk = o.k_is_last ? last : first;
     stride = static_cast<unsigned>(((kk + 31) / 32 + 3) / 4 * 4);
     bytes = static_cast<unsigned>((rows + 127) / 128 * 128) * stride;
+    // the reference's columnwise scale matrix of a member, compact: [pad4(first / 32), pad128(last)] (same bytes)
+    if (o.km_compact) stride = static_cast<unsigned>((rows + 127) / 128 * 128);
   };
   unsigned a_sc_run = 0, b_sc_run = 0;
   // MXFP8 contract (amd_ext.h): every member's FIRST dim is a multiple of 128.  The quantize kernels write a
@@ -1877,14 +1884,23 @@ GroupedOperandMeta pick_grouped_operand(const GroupedTensor &t, bool k_is_last, 
     m.ld = static_cast<unsigned>(gs.uniform_last);
   } else {
     NVTE_CHECK(t.has_columnwise_data(), "Grouped GEMM: ", name, " is missing column-wise data needed for TN layout");
-    // MXFP8: the contraction runs over the members' stored rows, which the gfx950 MFMA path can only read
-    // from the per-member TRANSPOSED columnwise layout (amd_ext.h) - the twin of the per-tensor rule above
-    NVTE_CHECK(!mx || t.columnwise_transposed, "Grouped GEMM: MXFP8 ", name,
-               " is read along its first dimension: quantize it with the transposed columnwise layout "
-               "(nvte_amd_set_grouped_columnwise_transposed)");
     m.base = static_cast<const uint8_t *>(t.columnwise_data.ptr);
     sinv = t.columnwise_scale_inv.ptr;
     dtype = t.columnwise_data.dtype;
+    if (mx && !t.columnwise_transposed) {
+      // the reference's columnwise layout (ref cublaslt_grouped_gemm.cu:551-565 hands it to cuBLASLt as a non-TN
+      // operand): members un-transposed [first_i, last], scales per member [pad4(first_i / 32), pad128(last)]
+      // (compact) or GEMM-swizzled as [pad128(last), pad4(first_i / 32)] - read K-major like the dense GEMM does
+      const GroupShapes gs = group_shapes_of(t);
+      NVTE_CHECK(t.last_dims.ptr == nullptr && gs.uniform_last > 0 && gs.uniform_last % 16 == 0 &&
+                     gs.uniform_last < (1ll << 31),
+                 "Grouped GEMM: MXFP8 ", name, " in the reference's columnwise layout is read K-major and needs one "
+                 "last dimension for all members, a multiple of 16 (or quantize it with the transposed columnwise "
+                 "layout, nvte_amd_set_grouped_columnwise_transposed)");
+      m.k_major = 1;
+      m.ld = static_cast<unsigned>(gs.uniform_last);
+      m.km_compact = t.with_gemm_swizzled_scales ? 0 : 1;
+    }
   }
   m.k_is_last = k_is_last ? 1 : 0;
   if (mx) m.e8m0 = static_cast<const uint8_t *>(sinv); else m.scale_inv = static_cast<const float *>(sinv);
@@ -2053,7 +2069,20 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   (void)api;
   g.ldP = B.ld;
   g.ldQ = A.ld;
-  if (mx) {
+  if (mx && (A.k_major || B.k_major)) {
+    // (bit 0 / 1: P / Q K-major, bit 2 / 3: that operand's scales are compact - as in gemm_impl)
+    NVTE_CHECK(A.k_major, "Grouped GEMM: MXFP8 B in the reference's columnwise layout needs A in it too (wgrad); "
+               "quantize B with the transposed columnwise layout (nvte_amd_set_grouped_columnwise_transposed)");
+    NVTE_CHECK(!B.k_major || A.km_compact == B.km_compact, "Grouped GEMM: MXFP8 A and B in the reference's columnwise "
+               "layout must both carry compact or both GEMM-swizzled scales");
+    const int km = (B.k_major ? 1 : 0) | 2 | ((B.k_major && B.km_compact) ? 4 : 0) | (A.km_compact ? 8 : 0);
+    switch (km) {
+      case 2: launch_by_format<true, false, true, 2>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+      case 10: launch_by_format<true, false, true, 10>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+      case 3: launch_by_format<true, false, true, 3>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+      default: launch_by_format<true, false, true, 15>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream); break;
+    }
+  } else if (mx) {
     launch_by_format<true, false, true>(fmt_of(b_dtype), fmt_of(a_dtype), g, stream);
   } else {
     switch ((B.k_major ? 1 : 0) | (A.k_major ? 2 : 0)) {

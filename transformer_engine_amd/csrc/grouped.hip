@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void group_cast_transpose_kernel(
 // member's last, partial 32-row block are skipped (nothing outside the member is read or written).
 //   ROW  : payload [first_i, last] at the member offset, scales at the member's GLOBAL rows of the
 //          [pad128(sum first), pad4(last/32)] matrix (compact or GEMM-swizzled)
-//   COL  : reference layout - payload un-transposed, scales [sum first / 32, pad128(last)]
+//   COL  : reference layout - payload un-transposed, scales compact [sum first / 32, pad128(last)] (= the members'
+//          [first_i / 32, pad128(last)] matrices back to back) or GEMM-swizzled per member like TCOL's
 //   TCOL : per-member transposed payload [last, first_i], scales [pad128(last), first_i/32] per member at
 //          pad128(last) * (member's first row / 32) (grouped columnwise_transposed, amd_ext.h)
 __host__ __device__ __forceinline__ size_t mx_swizzled_idx(size_t i, size_t j, size_t tiles_x) {
@@ -341,17 +342,21 @@ __global__ __launch_bounds__(256) void group_mxfp8_kernel(
           // (members that break the 128-row contract could otherwise run past the buffer)
           if (idx < sc_col_cap) sc_col[idx] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
         }
+      } else if constexpr (SWZ) {
+        // GEMM-swizzled: every member has a scale matrix of its own, [pad128(last), pad4(first_i / 32)] swizzled,
+        // behind those of the members before it (ref group_quantize_mxfp8.cuh:114-126) - the bytes of TCOL
+        const size_t sb = pad_cols * (row_start / 32);
+        const size_t blk = tile_r * 4 + w;
+        const size_t stride_c = (rows / 32 + 3) / 4 * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const size_t idx = sb + mx_swizzled_idx(col0 + j, blk, stride_c / 4);
+          if (idx < sc_col_cap) sc_col[idx] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
+        }
       } else {
         const size_t blk = (row_start + tile_r * kTile) / 32 + w;  // block of the whole group
-        if constexpr (SWZ) {
-          const size_t tiles_x = ceil_div_dev(ceil_div_dev(total_rows, 32), 4);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            sc_col[mx_swizzled_idx(col0 + j, blk, tiles_x)] = static_cast<uint8_t>(ebytes[j >> 2] >> (8 * (j & 3)));
-        } else {
-          u32x2 v = {ebytes[0], ebytes[1]};
-          *reinterpret_cast<u32x2 *>(sc_col + blk * pad_cols + col0) = v;
-        }
+        u32x2 v = {ebytes[0], ebytes[1]};
+        *reinterpret_cast<u32x2 *>(sc_col + blk * pad_cols + col0) = v;
       }
     }
   }

@@ -30,12 +30,15 @@ from .tensor import Float8CurrentScalingQuantizer, Float8Quantizer, MXFP8Quantiz
 
 
 class GroupedLinearFP8State:
-    def __init__(self, recipe, num_gemms: int, device=None, fp8_transposes: Optional[str] = None):
+    def __init__(self, recipe, num_gemms: int, device=None, fp8_transposes: Optional[str] = None,
+                 mx_columnwise: Optional[str] = None):
         """fp8_transposes (per-tensor FP8 recipes, the grouped-tensor path): "all" = transposed copies of X, W and dY per
         member, "none" = row-wise payloads only, the grouped dgrad / wgrad read them K-major (as LinearFP8State;
-        default NVTE_AMD_FP8_TRANSPOSES, else linear.FP8_TRANSPOSES_DEFAULT).  MXFP8 members always keep their
-        transposed columnwise copies; the legacy list path keeps all transposes."""
-        from .linear import FP8_TRANSPOSES_DEFAULT
+        default NVTE_AMD_FP8_TRANSPOSES, else linear.FP8_TRANSPOSES_DEFAULT).  The legacy list path keeps all
+        transposes.  mx_columnwise (MXFP8): "reference" = the members' columnwise copies keep the members' own shape
+        (what the reference's grouped quantize writes; the grouped GEMM reads them K-major), "transposed" = per-member
+        transposed copies (amd_ext.h); default NVTE_AMD_MX_COLUMNWISE, else linear.MX_COLUMNWISE_DEFAULT."""
+        from .linear import FP8_TRANSPOSES_DEFAULT, MX_COLUMNWISE_DEFAULT
         self.recipe, self.num_gemms = recipe, num_gemms
         self.device = device or torch.device("cuda")
         mode = fp8_transposes or os.environ.get("NVTE_AMD_FP8_TRANSPOSES") or FP8_TRANSPOSES_DEFAULT
@@ -47,10 +50,14 @@ class GroupedLinearFP8State:
             mk = lambda dt: Float8CurrentScalingQuantizer(dt, self.device, force_pow_2_scales=recipe.use_power_2_scales,
                                                           amax_epsilon=recipe.amax_epsilon)
         elif isinstance(recipe, MXFP8BlockScaling):
-            # member rows (m_splits) must be multiples of 128; columnwise copies per member, transposed (amd_ext.h)
+            # member rows (m_splits) must be multiples of 128; columnwise copies per member;
             # scales in the layout the grouped GEMM reads (ref module/grouped_linear.py:349, :864, :1905)
+            layout = mx_columnwise or os.environ.get("NVTE_AMD_MX_COLUMNWISE") or MX_COLUMNWISE_DEFAULT
+            if layout not in ("reference", "transposed", "mixed"):
+                raise ValueError(f"mx_columnwise must be 'reference' or 'transposed', got {layout!r}")
+
             def mk(dt):
-                q = MXFP8Quantizer(dt, columnwise_transposed=True)
+                q = MXFP8Quantizer(dt, columnwise_transposed=layout == "transposed")
                 q.optimize_for_gemm = True
                 return q
         elif isinstance(recipe, DelayedScaling):
