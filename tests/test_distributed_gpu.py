@@ -77,13 +77,20 @@ def _case_column(rank, world, dev, recipe_name, overlap):
     x8_g = D.gather_along_first_dim(x_local, None, quantizer=q)
     if recipe_name == "mxfp8":
         from transformer_engine_amd.tensor import MXFP8Quantizer
-        qf = MXFP8Quantizer(q.dtype, columnwise_transposed=True)
-        x8_full = qf(x_full)
-        assert torch.equal(x8_g._rowwise_data, x8_full._rowwise_data)
-        assert torch.equal(x8_g._rowwise_scale_inv[:world * M_local], x8_full._rowwise_scale_inv[:world * M_local])
-        assert torch.equal(x8_g._columnwise_data, x8_full._columnwise_data)
+        assert not q.columnwise_transposed        # the layers gather the reference layout (plain row gathers)
         nb = world * M_local // 32
-        assert torch.equal(x8_g._columnwise_scale_inv[:K, :nb], x8_full._columnwise_scale_inv[:K, :nb])
+        for tcol in (False, True):                # ... and the helper takes both
+            ql = MXFP8Quantizer(q.dtype, columnwise_transposed=tcol)
+            x8_g = D.gather_along_first_dim(x_local, None, quantizer=ql)
+            x8_full = MXFP8Quantizer(q.dtype, columnwise_transposed=tcol)(x_full)
+            assert x8_g._columnwise_transposed == tcol
+            assert torch.equal(x8_g._rowwise_data, x8_full._rowwise_data)
+            assert torch.equal(x8_g._rowwise_scale_inv[:world * M_local], x8_full._rowwise_scale_inv[:world * M_local])
+            assert torch.equal(x8_g._columnwise_data.view(-1), x8_full._columnwise_data.view(-1))
+            if tcol:
+                assert torch.equal(x8_g._columnwise_scale_inv[:K, :nb], x8_full._columnwise_scale_inv[:K, :nb])
+            else:
+                assert torch.equal(x8_g._columnwise_scale_inv[:nb, :K], x8_full._columnwise_scale_inv[:nb, :K])
     else:
         if recipe_name == "current":
             from transformer_engine_amd.tensor import Float8CurrentScalingQuantizer

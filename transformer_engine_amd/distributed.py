@@ -260,11 +260,12 @@ def _all_gather_fp8(q: Float8Tensor, group=None, need_transpose: bool = False) -
 
 
 def _all_gather_mxfp8(q: MXFP8Tensor, group=None) -> MXFP8Tensor:
-    """Gather rowwise data + rowwise e8m0 scales and - when present - the TRANSPOSED columnwise pair
-    (amd_ext.h layout: payload [K, m], scales [pad128(K), pad4(m/32)]), compact scales, padding stripped
-    and re-added (ref pytorch/distributed.py:1614-1659 gathers the reference's columnwise pair the same
-    way).  A rank's rows are a whole number of 32-row blocks, so the gathered transposed payload is the
-    per-rank payloads side by side: [K, tp*m]."""
+    """Gather rowwise data + rowwise e8m0 scales and - when present - the columnwise pair, compact scales, padding
+    stripped and re-added (ref pytorch/distributed.py:1614-1659).  A rank's rows are a whole number of 32-row
+    blocks.  Reference layout (payload [m, K], scales [pad4(m/32), pad128(K)]): the gathered pair is the ranks'
+    pairs one below the other - two more contiguous all-gathers, nothing is permuted; the GEMMs read it K-major.
+    Transposed layout (amd_ext.h: payload [K, m], scales [pad128(K), pad4(m/32)]): the gathered payload is the
+    per-rank payloads side by side, [K, tp*m], which costs a permuting copy after the gather."""
     assert not q._with_gemm_swizzled_scales, "all-gather needs compact (unswizzled) scales"
     tp = get_distributed_world_size(group)
     K = q.shape[-1]
@@ -276,12 +277,17 @@ def _all_gather_mxfp8(q: MXFP8Tensor, group=None) -> MXFP8Tensor:
         pad = (-rs.shape[0]) % 128
         if pad:
             rs = torch.cat([rs, torch.zeros(pad, rs.shape[1], dtype=rs.dtype, device=rs.device)])
-    if q._columnwise_data is not None:
-        if not q._columnwise_transposed:
-            raise NotImplementedError("all-gather of the reference-layout columnwise MXFP8 payload is not "
-                                      "implemented: quantize with columnwise_transposed=True")
-        if rows % 32 != 0:
-            raise ValueError("MXFP8 sequence-parallel shards need a multiple of 32 rows per rank")
+    transposed = q._columnwise_transposed
+    if q._columnwise_data is not None and rows % 32 != 0:
+        raise ValueError("MXFP8 sequence-parallel shards need a multiple of 32 rows per rank")
+    if q._columnwise_data is not None and not transposed:
+        nb = rows // 32
+        cd, _ = all_gather_rows(q._columnwise_data.view(rows, K), group)                       # [tp*m, K]
+        cs, _ = all_gather_rows(q._columnwise_scale_inv[:nb].contiguous(), group)              # [tp*nb, pad128(K)]
+        pad = (-cs.shape[0]) % 4
+        if pad:
+            cs = torch.cat([cs, torch.zeros(pad, cs.shape[1], dtype=cs.dtype, device=cs.device)])
+    elif q._columnwise_data is not None:
         nb = rows // 32
         cdl, _ = all_gather_rows(q._columnwise_data.view(1, K, rows), group)           # [tp, K, m]
         cd = cdl.permute(1, 0, 2).reshape(K, tp * rows).contiguous()
@@ -291,7 +297,7 @@ def _all_gather_mxfp8(q: MXFP8Tensor, group=None) -> MXFP8Tensor:
         cs[:K, :tp * nb] = cs_c
     return MXFP8Tensor(shape=(rows * tp, K), dtype=q.dtype, rowwise_data=rd, rowwise_scale_inv=rs,
                        columnwise_data=cd, columnwise_scale_inv=cs, fp8_dtype=q._fp8_dtype,
-                       quantizer=q._quantizer, columnwise_transposed=cd is not None)
+                       quantizer=q._quantizer, columnwise_transposed=cd is not None and transposed)
 
 
 def _mx_k_slice(w8: MXFP8Tensor, k0: int, k1: int) -> MXFP8Tensor:
@@ -372,6 +378,13 @@ def gather_along_first_dim(inp, group=None, quantizer=None, need_transpose: bool
     raise TypeError(type(inp))
 
 
+def _keep_weight_transposed(state) -> None:
+    from .linear import FWD_WEIGHT
+    qw = state.fwd_q[FWD_WEIGHT]
+    if isinstance(qw, MXFP8Quantizer):
+        qw.columnwise_transposed = True
+
+
 def configure_amax_reduction(quantizer, group) -> None:
     """A tensor that is sharded over `group` and gathered in FP8 must be quantized with ONE scale on
     every rank.  Current scaling: the amax is MAX-all-reduced over the group before the scale is
@@ -405,9 +418,11 @@ class ColumnParallelLinearSP:
         g = torch.Generator(device="cpu").manual_seed(4321 + rank)
         self.weight = (torch.randn(self.N_local, in_features, generator=g) * 0.02).to(params_dtype).to(self.device)
         # the gathered operand keeps compact MXFP8 scales (ref module/linear.py:2069)
-        # (MXFP8: the gathered operand's columnwise pair travels in the transposed layout, _all_gather_mxfp8)
+        # (MXFP8: the gathered operand's columnwise pair travels in the reference layout, _all_gather_mxfp8 - plain
+        # row gathers; the cached weight shard keeps the transposed one, dgrad's output-column pieces are row blocks of it)
         self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device, compact_mx_scales=("input",), fp8_transposes="all",
-                                    mx_columnwise="transposed")
+                                    mx_columnwise="reference")
+        _keep_weight_transposed(self.state)
         self.overlap = overlap
         self.chunks = chunks
         self.out_dtype = params_dtype
@@ -691,7 +706,7 @@ class RowParallelLinearSP:
         self.weight = (torch.randn(out_features, self.K_local, generator=g) * 0.02).to(params_dtype).to(self.device)
         # the gathered operand keeps compact MXFP8 scales (ref module/linear.py:2077)
         self.state = LinearFP8State(recipe or DelayedScaling(), device=self.device, compact_mx_scales=("grad_output",), fp8_transposes="all",
-                                    mx_columnwise="transposed")
+                                    mx_columnwise="reference")
         self.overlap, self.chunks, self.out_dtype = overlap, chunks, params_dtype
         # dY is sharded on tokens and gathered in FP8: one scale over the whole group
         configure_amax_reduction(self.state.bwd_q[BWD_GRAD_OUTPUT], group)
