@@ -2067,6 +2067,15 @@ void grouped_gemm_impl(const char *api, const GroupedCall &call, size_t G, bool 
   g.d_dtype = d_dtype;
   g.grid = cus;  // persistent: the tile count is only known on the device
   (void)api;
+  // as gemm_impl: an output too large to stay cached until someone reads it leaves through streaming stores
+  // (members that accumulate into C read it first and keep the plain stores)
+  size_t out_bytes = 0;
+  if (call.D != nullptr) {
+    out_bytes = call.D->data.numel() * dtype_bits(d_dtype) / 8;
+  } else {
+    for (size_t i = 0; i < G; ++i) out_bytes += lookup_checked(call.d_list[i])->data.numel() * dtype_bits(d_dtype) / 8;
+  }
+  g.nt_store = out_bytes > nt_store_bytes() ? 1u : 0u;
   g.ldP = B.ld;
   g.ldQ = A.ld;
   if (mx && (A.k_major || B.k_major)) {
