@@ -103,8 +103,9 @@ size_t nvte_get_grouped_gemm_setup_workspace_size(size_t num_tensors);
  * persistent launch; member shapes are read on the device.  FP8 per-tensor scaling operands
  * (scale_inv[i] per member) or MXFP8 operands (both A and B; ref cublaslt_grouped_gemm.cu:283-300; member
  * i's e8m0 scale matrix at the sum of the padded sizes before it, :1117-1198; compact or swizzled;
- * layouts that contract over a member's first dim need the transposed columnwise storage of
- * amd_ext.h), BF16/FP16/FP32 C and D.  C may be NULL (beta is then ignored) or D. */
+ * layouts that contract over a member's first dim read the reference's un-transposed columnwise members
+ * K-major, or the transposed columnwise storage of amd_ext.h), BF16/FP16/FP32 C and D.  C may be NULL (beta
+ * is then ignored) or D.  Per-tensor members without columnwise data are read K-major the same way. */
 void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
                        const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
                        const NVTETensor beta, NVTETensor workspace_setup, NVTETensor workspace_cublas,
@@ -116,7 +117,8 @@ void nvte_grouped_gemm(const NVTEGroupedTensor A, int transa, const NVTEGroupedT
  * address is resolved once per device (at nvte_cublas_handle_init() or at the first call on that
  * device).  The call allocates nothing.  Limits: at most nvte_amd_grouped_gemm_noalloc_max_tensors()
  * (256) member tensors, more is an error; every call on a GPU shares that GPU's array, so two calls
- * that overlap on one GPU (different streams) race - serialise them or use nvte_grouped_gemm. */
+ * that overlap on one GPU (different streams) race - serialise them or use nvte_grouped_gemm.  As for
+ * every entry point here, `stream` must belong to the CURRENT device (the array's address is that device's). */
 void nvte_amd_grouped_gemm_noalloc(const NVTEGroupedTensor A, int transa, const NVTEGroupedTensor B, int transb,
                                    const NVTEGroupedTensor C, NVTEGroupedTensor D, const NVTETensor alpha,
                                    const NVTETensor beta, NVTEGroupedMatmulConfig config, hipStream_t stream);
