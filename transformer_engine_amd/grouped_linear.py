@@ -97,10 +97,11 @@ class GroupedLinearFP8State:
             reduce_and_update_fp8_tensors([self.bwd_state], group)
 
 
-def _hp_out(first_dims: torch.Tensor, rows: int, cols: int, G: int, dtype) -> GroupedTensor:
+def _hp_out(first_dims: torch.Tensor, rows: int, cols: int, G: int, dtype, offsets=None) -> GroupedTensor:
     return GroupedTensor(num_tensors=G, logical_shape=(rows, cols), dtype=dtype,
                          rowwise_data=torch.empty(rows * cols, dtype=dtype, device=first_dims.device),
-                         first_dims=first_dims, tensor_offsets=splits_to_offsets(first_dims, cols))
+                         first_dims=first_dims,
+                         tensor_offsets=offsets if offsets is not None else splits_to_offsets(first_dims, cols))
 
 
 def grouped_linear_forward(x: torch.Tensor, weight: torch.Tensor, first_dims: torch.Tensor,
@@ -112,7 +113,9 @@ def grouped_linear_forward(x: torch.Tensor, weight: torch.Tensor, first_dims: to
     K = x.shape[-1]
     N = weight.shape[0] // G
     st.q_input.set_usage(rowwise=True, columnwise=needs_backward and st.keep_transposes)
-    x8 = group_quantize(x, st.q_input, G, first_dims=first_dims)
+    # the member offsets of the [*, K] and [*, N] tensors: one scan each per step (X and dX, Y and dY share them)
+    offs_k, offs_n = splits_to_offsets(first_dims, K), splits_to_offsets(first_dims, N)
+    x8 = group_quantize(x, st.q_input, G, first_dims=first_dims, tensor_offsets=offs_k)
     if st.weight_cache is None or is_first_microbatch is None or is_first_microbatch:
         st.q_weight.set_usage(rowwise=True, columnwise=needs_backward and st.keep_transposes)
         w8 = group_quantize(weight, st.q_weight, G)
@@ -120,20 +123,20 @@ def grouped_linear_forward(x: torch.Tensor, weight: torch.Tensor, first_dims: to
             st.weight_cache = w8
     else:
         w8 = st.weight_cache
-    out = _hp_out(first_dims, x.shape[0], N, G, x.dtype)
+    out = _hp_out(first_dims, x.shape[0], N, G, x.dtype, offs_n)
     general_grouped_gemm_for_grouped_tensor(w8, x8, out, layout="TN")
-    return out.rowwise_data.view(x.shape[0], N), (x8, w8, K, N)
+    return out.rowwise_data.view(x.shape[0], N), (x8, w8, K, N, offs_k, offs_n)
 
 
 def grouped_linear_backward(dy: torch.Tensor, saved, first_dims: torch.Tensor, st: GroupedLinearFP8State, *,
                             wgrad_out: Optional[List[torch.Tensor]] = None, accumulate_wgrad: bool = False):
     """Returns (dx [sum m_i, K], list of dW_i [N, K])."""
-    x8, w8, K, N = saved
+    x8, w8, K, N, offs_k, offs_n = saved
     G = st.num_gemms
     dy = dy if dy.is_contiguous() else dy.contiguous()
     st.q_grad.set_usage(rowwise=True, columnwise=st.keep_transposes)
-    dy8 = group_quantize(dy, st.q_grad, G, first_dims=first_dims)
-    dx = _hp_out(first_dims, dy.shape[0], K, G, dy.dtype)
+    dy8 = group_quantize(dy, st.q_grad, G, first_dims=first_dims, tensor_offsets=offs_n)
+    dx = _hp_out(first_dims, dy.shape[0], K, G, dy.dtype, offs_k)
     general_grouped_gemm_for_grouped_tensor(w8, dy8, dx, layout="NN")
     if wgrad_out is None:
         wgrad_out = [torch.empty(N, K, dtype=dy.dtype, device=dy.device) for _ in range(G)]
