@@ -72,8 +72,8 @@ int is64_of(const Tensor &t, const char *what) {
 }
 
 // ---------------------------------------------------------------- grouped amax
-constexpr int kAmaxChunk = 256 * 8 * 16;  // elements per workgroup: the two member lookups (dependent
-                                           // global loads) are paid once per 64 KiB of bf16 input
+constexpr int kAmaxChunk = 256 * 8 * 32;  // elements per workgroup: the two member lookups (dependent
+                                           // global loads) are paid once per 128 KiB of bf16 input
 
 __global__ void group_zero_amax_kernel(float *amax, unsigned n, const float *noop) {
   if (noop_set(noop)) return;
@@ -105,7 +105,19 @@ __global__ __launch_bounds__(256) void group_amax_kernel(const IT *__restrict__ 
     const int64_t head_end = body0 < s1 ? body0 : s1;
     for (int64_t e = s0 + threadIdx.x; e < head_end; e += 256) m = fmaxf(m, __builtin_fabsf(widen(in[e])));
     int64_t i = body0 + threadIdx.x * 8;
-    for (; i + 256 * 8 + 8 <= s1; i += 2 * 256 * 8) {  // two independent vectors in flight
+    for (; i + 3 * 256 * 8 + 8 <= s1; i += 4 * 256 * 8) {  // four independent vectors in flight
+      float f[8], h[8], f2[8], h2[8];
+      Load8<IT>::run(in + i, f);
+      Load8<IT>::run(in + i + 256 * 8, h);
+      Load8<IT>::run(in + i + 2 * 256 * 8, f2);
+      Load8<IT>::run(in + i + 3 * 256 * 8, h2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        m = fmaxf(m, fmaxf(__builtin_fabsf(f[k]), __builtin_fabsf(f2[k])));
+        m1 = fmaxf(m1, fmaxf(__builtin_fabsf(h[k]), __builtin_fabsf(h2[k])));
+      }
+    }
+    for (; i + 256 * 8 + 8 <= s1; i += 2 * 256 * 8) {  // two
       float f[8], h[8];
       Load8<IT>::run(in + i, f);
       Load8<IT>::run(in + i + 256 * 8, h);
