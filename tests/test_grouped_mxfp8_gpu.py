@@ -249,8 +249,9 @@ def test_grouped_gemm_mxfp8_member_off_the_128_contract_is_loud():
             r0 += m
 
 
+@pytest.mark.parametrize("sm_count", [0, 10])
 @pytest.mark.parametrize("swizzled", [False, True])
-def test_grouped_gemm_mxfp8_reference_columnwise_layout_equals_transposed(swizzled):
+def test_grouped_gemm_mxfp8_reference_columnwise_layout_equals_transposed(swizzled, sm_count):
     """(Round 2 refused the reference's columnwise layout here.)  dgrad and wgrad on members in the reference layout
     are bit-equal to the same GEMMs on the transposed copies: same tiles, same K order.  Ragged members, an empty
     one, tiles past the member's rows (N = 384 is 1.5 tiles)."""
@@ -267,9 +268,10 @@ def test_grouped_gemm_mxfp8_reference_columnwise_layout_equals_transposed(swizzl
         w8 = group_quantize(w, mk(E4), G)
         dy8 = group_quantize(dy, mk(E5), G, first_dims=fd)
         dx = _hp(fd, M, K, G)
-        general_grouped_gemm_for_grouped_tensor(w8, dy8, dx, layout="NN")
+        cap = 0 if tcol else sm_count      # (the K-major launch also with a capped, odd workgroup count)
+        general_grouped_gemm_for_grouped_tensor(w8, dy8, dx, layout="NN", sm_count=cap)
         dws = [torch.full((N, K), float("nan"), dtype=torch.float32, device="cuda") for _ in range(G)]
-        general_grouped_gemm_for_grouped_tensor(x8, dy8, dws, layout="NT")
+        general_grouped_gemm_for_grouped_tensor(x8, dy8, dws, layout="NT", sm_count=cap)
         torch.cuda.synchronize()
         outs[tcol] = (dx.rowwise_data.clone(), [d.clone() for d in dws], x8, dy8)
     assert torch.equal(outs[True][0], outs[False][0])
