@@ -318,6 +318,30 @@ def test_mxfp8_gemm_reference_columnwise_layout_exact_integers():
     assert torch.equal(dw.double(), ref_dw)
 
 
+@pytest.mark.parametrize("tcol", [False, True])
+def test_mxfp8_gemm_compact_scales_swizzled_first_equals_direct(tcol, monkeypatch):
+    """general_gemm swizzles compact MXFP8 scales before a LARGE GEMM (the reference's wrapper always does, ref
+    pytorch/csrc/extensions/gemm.cpp) and lets the kernel read them directly otherwise: the same scales either way, so
+    the results are bit-equal - TN, NN, NT, both columnwise layouts, the reference one at sizes off the tile grid."""
+    from transformer_engine_amd import gemm as G
+    M, N, K = (384, 640, 512) if tcol else (416, 640, 352)    # (the transposed layout needs 128-multiples)
+    q = MXFP8Quantizer(E4, columnwise_transposed=tcol)          # compact scales
+    qg = MXFP8Quantizer(E5, columnwise_transposed=tcol)
+    x, w, dy = q(randn_input((M, K), torch.bfloat16, 71)), q(randn_input((N, K), torch.bfloat16, 72, scale=0.05)), \
+        qg(randn_input((M, N), torch.bfloat16, 73, scale=0.01))
+    outs = {}
+    for first in (0, 1 << 62):
+        monkeypatch.setattr(G, "_SWIZZLE_FIRST_MACS", first)
+        y, *_ = general_gemm(w, x, out_dtype=torch.float32, layout="TN")
+        dx, *_ = general_gemm(w, dy, out_dtype=torch.float32, layout="NN", grad=True)
+        dw, *_ = general_gemm(x, dy, out_dtype=torch.float32, layout="NT", grad=True)
+        torch.cuda.synchronize()
+        outs[first] = (y, dx, dw)
+    for a, b in zip(outs[0], outs[1 << 62]):
+        assert torch.equal(a, b) and not torch.isnan(a).any()
+    assert not x._with_gemm_swizzled_scales          # the caller's tensors are left as they were
+
+
 def test_mxfp8_gemm_k_major_argument_errors():
     """What the K-major path does not take is refused loudly, never computed wrongly."""
     from transformer_engine_amd._lib import NVTEError

@@ -446,7 +446,15 @@ void swizzle_tensor(const Tensor &in, Tensor &out, bool forward, hipStream_t str
   const bool has_r = in.scale_inv.present(), has_c = in.columnwise_scale_inv.present();
   NVTE_CHECK(has_r || has_c, "Input tensor has no scaling factors");
   if (has_r) swizzle_one(in.scale_inv, out.scale_inv, forward, "rowwise", stream);
-  if (has_c) swizzle_col(in.columnwise_scale_inv, out.columnwise_scale_inv, forward, stream);
+  if (has_c) {
+    NVTE_CHECK(in.columnwise_transposed == out.columnwise_transposed, "input and output column-wise layouts differ");
+    // transposed columnwise layout (amd_ext.h): the scale matrix [pad128(cols), pad4(rows / 32)] is already
+    // row-per-GEMM-row, i.e. swizzles like a row-wise one
+    if (in.columnwise_transposed)
+      swizzle_one(in.columnwise_scale_inv, out.columnwise_scale_inv, forward, "columnwise (transposed)", stream);
+    else
+      swizzle_col(in.columnwise_scale_inv, out.columnwise_scale_inv, forward, stream);
+  }
 }
 
 // ref swizzle/swizzle.cu:2467-2481 (swizzle_grouped_scaling_factors): every member of a SAME-SHAPE MXFP8

@@ -76,6 +76,7 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
         raise ValueError("Trying to use non-zero beta while not accumulating into D tensor. "
                          "Beta has nothing to be applied to.")
 
+    A, B = _swizzle_compact_mx_scales(A, B, transa, transb)
     wa, a_shape = _wrap_operand(A)
     wb, b_shape = _wrap_operand(B)
     out_shape = gemm_output_shape(a_shape, b_shape, transa, transb)
@@ -186,6 +187,54 @@ def general_gemm(A, B, out_dtype: Optional[torch.dtype] = None, quantization_par
             if w is not None:
                 w.destroy()
     return _finish(hp_out), bias_grad, gelu_input, extra_output
+
+
+# MXFP8 operands with COMPACT scales (a gathered operand, the output of a fused norm): the reference's GEMM wrapper
+# swizzles them first (ref pytorch/csrc/extensions/gemm.cpp swizzle_scales_for_gemm); the kernel here also reads the
+# compact layout directly, 8 % slower (one 128-byte line per tile row and K tile instead of 512 contiguous bytes per 128
+# rows).  From this many multiply-adds on, a swizzle pass over the 1/32-size scale matrix (about 5 us) is the cheaper way.
+_SWIZZLE_FIRST_MACS = 1 << 37
+
+
+def _swizzled_scales_copy(t: MXFP8Tensor, rowwise: bool) -> MXFP8Tensor:
+    data = t._rowwise_data if rowwise else t._columnwise_data
+    sc = t._rowwise_scale_inv if rowwise else t._columnwise_scale_inv
+    if data is None or sc is None:
+        return t            # the library reports the missing usage itself
+    def view(scales, swizzled):
+        return MXFP8Tensor(shape=t._shape, dtype=t.dtype, rowwise_data=data if rowwise else None,
+                           rowwise_scale_inv=scales if rowwise else None,
+                           columnwise_data=None if rowwise else data,
+                           columnwise_scale_inv=None if rowwise else scales, fp8_dtype=t._fp8_dtype,
+                           quantizer=t._quantizer, with_gemm_swizzled_scales=swizzled,
+                           columnwise_transposed=(not rowwise) and t._columnwise_transposed)
+    src, dst = view(sc, False), view(torch.empty_like(sc), True)
+    wi, wo = src.wrap(), dst.wrap()
+    try:
+        api.nvte_swizzle_scaling_factors(wi.handle, wo.handle, current_stream_ptr())
+    finally:
+        wi.destroy(); wo.destroy()
+    return dst
+
+
+def _swizzle_compact_mx_scales(A, B, transa: bool, transb: bool):
+    if not (isinstance(A, MXFP8Tensor) and isinstance(B, MXFP8Tensor)):
+        return A, B
+    if A._with_gemm_swizzled_scales and B._with_gemm_swizzled_scales:
+        return A, B
+    if A.numel() == 0 or B.numel() == 0:
+        return A, B
+    a0, a1 = _flat2d(A.shape)
+    b0, b1 = _flat2d(B.shape)
+    m, k = (a0, a1) if transa else (a1, a0)
+    n = b1 if transb else b0
+    if m * n * k < _SWIZZLE_FIRST_MACS:
+        return A, B
+    if not A._with_gemm_swizzled_scales:
+        A = _swizzled_scales_copy(A, rowwise=transa)
+    if not B._with_gemm_swizzled_scales:
+        B = _swizzled_scales_copy(B, rowwise=not transb)
+    return A, B
 
 
 def multi_gemm(entries, grad: bool = False):
